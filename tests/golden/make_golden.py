@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from oracle/gs_oracle.py.
+
+The reference holds no byte-level vectors for this path,
+so these fixtures are produced by the big-integer oracle, whose own pinning is
+described in its header.  All values are canonical integers in hex (NOT
+Montgomery form); tests convert at the boundary.
+
+Statements follow the reference's tests: tests/prover.rs:25-172 (X=[2g,3g],
+Y=[4g], Gamma=[[5],[0]], A=[c1], B=[O,c2]) for each of the four equation types,
+plus dense random instances of the BASELINE shape.
+
+Usage:  python tests/golden/make_golden.py [bls12_381] [bn254]
+"""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import gs_oracle as O  # noqa: E402
+
+
+def enc_fr_mat(m):
+    return [[O.hx(v) for v in row] for row in m]
+
+
+def enc_vars(ty, side, vs):
+    if side == "x":
+        isg = ty in (O.PPE, O.MSMEG1)
+        return [O.enc_g1(v) if isg else O.hx(v) for v in vs]
+    isg = ty in (O.PPE, O.MSMEG2)
+    return [O.enc_g2(v) if isg else O.hx(v) for v in vs]
+
+
+def enc_target(ty, t):
+    if ty == O.PPE:
+        return O.enc_f12(t)
+    if ty == O.MSMEG1:
+        return O.enc_g1(t)
+    if ty == O.MSMEG2:
+        return O.enc_g2(t)
+    return O.hx(t)
+
+
+def target_for(ty, crs, xs_dl, ys_dl, a_dl, b_dl, gamma):
+    """Satisfied target from discrete logs w.r.t. the CRS generators:
+    s = sum a_j y_j + sum x_i b_i + sum x_i gamma_ij y_j."""
+    s = sum(a * y for a, y in zip(a_dl, ys_dl))
+    s += sum(x * b for x, b in zip(xs_dl, b_dl))
+    s += sum(xs_dl[i] * gamma[i][j] * ys_dl[j] for i in range(len(xs_dl)) for j in range(len(ys_dl)))
+    s %= O.R
+    if ty == O.PPE:
+        return O.f12_pow(crs["gt"], s)
+    if ty == O.MSMEG1:
+        return O.g1_mul(s, crs["g1"])
+    if ty == O.MSMEG2:
+        return O.g2_mul(s, crs["g2"])
+    return s
+
+
+def make_case(name, ty, crs, rng, xs_dl, ys_dl, a_dl, b_dl, gamma, do_verify=True, tamper=None):
+    m, n = len(xs_dl), len(ys_dl)
+    g1, g2 = crs["g1"], crs["g2"]
+    x_is_g = ty in (O.PPE, O.MSMEG1)
+    y_is_g = ty in (O.PPE, O.MSMEG2)
+    xvars = [O.g1_mul(x, g1) if x_is_g else x for x in xs_dl]
+    yvars = [O.g2_mul(y, g2) if y_is_g else y for y in ys_dl]
+    # A pairs with Y: lives on the G1 side iff X does; B pairs with X
+    a_consts = [(O.g1_mul(a, g1) if a else None) if x_is_g else a for a in a_dl]
+    b_consts = [(O.g2_mul(b, g2) if b else None) if y_is_g else b for b in b_dl]
+    target = target_for(ty, crs, xs_dl, ys_dl, a_dl, b_dl, gamma)
+    equ = {"type": ty, "a": a_consts, "b": b_consts, "gamma": gamma, "target": target}
+    # draw order of the reference: R row-major, S row-major, T row-major
+    Rm = [[rng.fr() for _ in range(2 if x_is_g else 1)] for _ in range(m)]
+    Sm = [[rng.fr() for _ in range(2 if y_is_g else 1)] for _ in range(n)]
+    T = [[rng.fr() for _ in range(2 if x_is_g else 1)] for _ in range(2 if y_is_g else 1)]
+    t0 = time.time()
+    xc, yc, pi, theta = O.commit_and_prove(equ, xvars, yvars, Rm, Sm, T, crs)
+    case = {
+        "name": name,
+        "type": ty,
+        "m": m,
+        "n": n,
+        "a": enc_vars(ty, "x", a_consts),
+        "b": enc_vars(ty, "y", b_consts),
+        "gamma": enc_fr_mat(gamma),
+        "target": enc_target(ty, target),
+        "xvars": enc_vars(ty, "x", xvars),
+        "yvars": enc_vars(ty, "y", yvars),
+        "R": enc_fr_mat(Rm),
+        "S": enc_fr_mat(Sm),
+        "T": enc_fr_mat(T),
+        "xcoms": [[O.enc_g1(c[0]), O.enc_g1(c[1])] for c in xc],
+        "ycoms": [[O.enc_g2(c[0]), O.enc_g2(c[1])] for c in yc],
+        "pi": [[O.enc_g2(c[0]), O.enc_g2(c[1])] for c in pi],
+        "theta": [[O.enc_g1(c[0]), O.enc_g1(c[1])] for c in theta],
+    }
+    if do_verify:
+        ok = O.verify(equ, xc, yc, pi, theta, crs)
+        assert ok, name
+        case["verify"] = True
+        # negative twins (the reference has none; SURVEY 8c asks for them)
+        neg = []
+        bad_theta = [(theta[0][0], O.g1_add(theta[0][1], g1))] + theta[1:]
+        assert not O.verify(equ, xc, yc, pi, bad_theta, crs)
+        neg.append({"what": "theta[0].1 += g1", "verify": False})
+        bad_pi = [(O.g2_add(pi[0][0], g2), pi[0][1])] + pi[1:]
+        assert not O.verify(equ, xc, yc, bad_pi, theta, crs)
+        neg.append({"what": "pi[0].0 += g2", "verify": False})
+        case["negative"] = neg
+    print("   case %-28s %.1fs" % (name, time.time() - t0))
+    sys.stdout.flush()
+    return case
+
+
+def build(curve):
+    O.set_curve(curve)
+    rng = O.SplitMix64(20241220 + curve.curve_id)
+    out = {
+        "curve": curve.name,
+        "note": "canonical integers, hex; produced by oracle/gs_oracle.py; pairing exponent = arkworks convention "
+        "(textbook reduced ate ^ fe_cofactor) [ark-mem] -- parity unpinned at byte level",
+        "p": O.hx(curve.p),
+        "r": O.hx(curve.r),
+    }
+    g1s, g2s = curve.g1, curve.g2
+    # --- arithmetic KATs -----------------------------------------------------
+    ks = [1, 2, 3, 0xDEADBEEF, rng.fr(), rng.fr(), curve.r - 1]
+    out["g1_smul"] = [{"k": O.hx(k), "out": O.enc_g1(O.g1_mul(k, g1s))} for k in ks]
+    out["g2_smul"] = [{"k": O.hx(k), "out": O.enc_g2(O.g2_mul(k, g2s))} for k in ks]
+    a, b = rng.fr(), rng.fr()
+    pa, qb = O.g1_mul(a, g1s), O.g2_mul(b, g2s)
+    out["pairing"] = [
+        {"p": O.enc_g1(g1s), "q": O.enc_g2(g2s), "out": O.enc_f12(O.pairing(g1s, g2s))},
+        {"p": O.enc_g1(pa), "q": O.enc_g2(qb), "out": O.enc_f12(O.pairing(pa, qb))},
+    ]
+    fa = O.pairing(pa, qb)
+    fb = O.pairing(g1s, qb)
+    out["fp12"] = {
+        "a": O.enc_f12(fa),
+        "b": O.enc_f12(fb),
+        "mul": O.enc_f12(O.f12_mul(fa, fb)),
+        "sqr": O.enc_f12(O.f12_sqr(fa)),
+        "inv": O.enc_f12(O.f12_inv(fa)),
+        "conj": O.enc_f12(O.f12_conj(fa)),
+        "frob1": O.enc_f12(O.frob_fp12(fa, 1)),
+        "frob2": O.enc_f12(O.frob_fp12(fa, 2)),
+    }
+    # --- CRS of the reference's shape (generator.rs:81-118) ---------------------
+    alpha, beta, a1, a2, t1, t2 = [rng.fr() for _ in range(6)]
+    p1, p2 = O.g1_mul(alpha, g1s), O.g2_mul(beta, g2s)
+    crs = O.make_crs(p1, p2, a1, a2, t1, t2)
+    out["crs"] = {
+        "u": [[O.enc_g1(c[0]), O.enc_g1(c[1])] for c in crs["u"]],
+        "v": [[O.enc_g2(c[0]), O.enc_g2(c[1])] for c in crs["v"]],
+        "g1": O.enc_g1(crs["g1"]),
+        "g2": O.enc_g2(crs["g2"]),
+        "gt": O.enc_f12(crs["gt"]),
+    }
+    # --- L2 hooks: pairing_sum, left_mul ---------------------------------------
+    xs = [(O.g1_mul(rng.fr(), p1), O.g1_mul(rng.fr(), p1)) for _ in range(3)]
+    xs[1] = (None, xs[1][1])
+    ys = [(O.g2_mul(rng.fr(), p2), O.g2_mul(rng.fr(), p2)) for _ in range(3)]
+    ys[2] = (ys[2][0], None)
+    out["pairing_sum"] = {
+        "x": [[O.enc_g1(c[0]), O.enc_g1(c[1])] for c in xs],
+        "y": [[O.enc_g2(c[0]), O.enc_g2(c[1])] for c in ys],
+        "out": [O.enc_f12(f) for f in O.comt_pairing_sum(xs, ys)],
+    }
+    lm = [[rng.fr() for _ in range(3)] for _ in range(2)]
+    lm[1][0] = 0
+    out["left_mul"] = {
+        "lhs": enc_fr_mat(lm),
+        "com1": [[O.enc_g1(c[0]), O.enc_g1(c[1])] for c in xs],
+        "com2": [[O.enc_g2(c[0]), O.enc_g2(c[1])] for c in ys],
+        "out1": [[O.enc_g1(c[0]), O.enc_g1(c[1])] for c in O.com1_left_mul(xs, lm)],
+        "out2": [[O.enc_g2(c[0]), O.enc_g2(c[1])] for c in O.com2_left_mul(ys, lm)],
+    }
+    # --- equation cases -----------------------------------------------------------
+    cases = []
+    names = {O.PPE: "ppe", O.MSMEG1: "msmeg1", O.MSMEG2: "msmeg2", O.QUAD: "quad"}
+    for ty in (O.PPE, O.MSMEG1, O.MSMEG2, O.QUAD):
+        # tests/prover.rs: X=[2,3]g, Y=[4]g, A=[c1], B=[0,c2], Gamma=[[5],[0]]
+        c1, c2 = rng.fr(), rng.fr()
+        cases.append(
+            make_case(names[ty] + "_ref_2x1", ty, crs, rng, [2, 3], [4], [c1], [0, c2], [[5], [0]])
+        )
+    for ty in (O.PPE, O.MSMEG1, O.MSMEG2, O.QUAD):
+        m, n = 2, 2
+        cases.append(
+            make_case(
+                names[ty] + "_dense_2x2", ty, crs, rng,
+                [rng.fr() for _ in range(m)], [rng.fr() for _ in range(n)],
+                [rng.fr() for _ in range(n)], [rng.fr() for _ in range(m)],
+                [[rng.fr() for _ in range(n)] for _ in range(m)],
+            )
+        )
+    # the BASELINE shape: PPE, m = n = 4, dense Gamma
+    for k in range(2):
+        m, n = 4, 4
+        cases.append(
+            make_case(
+                "ppe_dense_4x4_%d" % k, O.PPE, crs, rng,
+                [rng.fr() for _ in range(m)], [rng.fr() for _ in range(n)],
+                [rng.fr() for _ in range(n)], [rng.fr() for _ in range(m)],
+                [[rng.fr() for _ in range(n)] for _ in range(m)],
+                do_verify=(k == 0),
+            )
+        )
+    # ragged shape + zero gamma row + identity witness
+    cases.append(
+        make_case(
+            "ppe_ragged_3x1", O.PPE, crs, rng, [rng.fr(), 0, rng.fr()], [rng.fr()], [0], [rng.fr(), rng.fr(), 0],
+            [[rng.fr()], [0], [0]],
+        )
+    )
+    out["cases"] = cases
+    return out
+
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or ["bls12_381", "bn254"]
+    for c in (O.BLS12_381, O.BN254):
+        if c.name in want:
+            print("building", c.name)
+            O.set_curve(c)
+            O.selfcheck(verbose=False)
+            t0 = time.time()
+            data = build(c)
+            path = os.path.join(HERE, c.name + ".json")
+            with open(path, "w") as f:
+                json.dump(data, f, indent=0, separators=(",", ":"))
+                f.write("\n")
+            print("wrote %s (%.0f s, %d bytes)" % (path, time.time() - t0, os.path.getsize(path)))
+    O.set_curve(O.BLS12_381)
