@@ -1,0 +1,217 @@
+// Optimal-ate pairing pieces: Miller-loop doubling/addition steps on the twist
+// in homogeneous projective coordinates, sparse line multiplication, and the
+// final exponentiation with ARKWORKS' exponent.
+//
+// Replaces E::pairing / E::multi_pairing (ark-ec ^0.5 models::bls12 / models::bn,
+// external to the reference; call sites src/data_structures.rs:484-502).
+// Result-defining convention: for BLS12 the hard part raises to
+// (x-1)^2 (x+p)(x^2+p^2-1) + 3 = 3 (p^4-p^2+1)/r  (eprint 2020/875), i.e. the
+// cube of the textbook reduced pairing.  Any Miller-loop variant is admissible:
+// factors in proper subfields vanish under the final exponentiation and the
+// fully exponentiated value is unique.
+//
+// Line derivation (M-type twist, untwist (x',y') -> (x'/w^2, y'/w^3)): the
+// tangent/chord through T with twist-slope L evaluated at P=(xP,yP), scaled by
+// w^3 (in Fp4) and an Fp2 factor, is
+//     l = ell0 + (ellx * xP) w^2 + (elly * yP) w^3
+// with w^2 = v (slot 1) and w^3 = v w (slot 4): f.mul_by_014.  D-type twist:
+//     l = (elly * yP) + (ellx * xP) w + ell0 w^3 : f.mul_by_034.
+#pragma once
+#include "gs_curve.cuh"
+
+namespace gs {
+
+template <class C> struct Proj2 {  // homogeneous projective point on the twist
+  Fp2<C> x, y, z;
+};
+template <class C> struct Line {
+  Fp2<C> l0, lx, ly;
+};
+
+template <class C> GS_HD Fp2<C> twist_b3() {
+  Fp2<C> r;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) {
+    r.c0.v[i] = C::B2X3[0][i];
+    r.c1.v[i] = C::B2X3[1][i];
+  }
+  return r;
+}
+
+// T <- 2T, returns the tangent line coefficients.
+template <class C> GS_HD_NOINLINE void miller_dbl(Proj2<C>& t, Line<C>& l) {
+  Fp2<C> a = half(mul(t.x, t.y));
+  Fp2<C> b = sqr(t.y);
+  Fp2<C> c = sqr(t.z);
+  Fp2<C> e = mul(twist_b3<C>(), c);  // 3 b' Z^2
+  Fp2<C> f = add(dbl(e), e);         // 9 b' Z^2
+  Fp2<C> g = half(add(b, f));
+  Fp2<C> h = sub(sqr(add(t.y, t.z)), add(b, c));  // 2 Y Z
+  Fp2<C> j = sqr(t.x);
+  Fp2<C> e2 = sqr(e);
+  l.l0 = sub(b, e);                 // Y^2 - 3 b' Z^2
+  l.lx = neg(add(dbl(j), j));       // -3 X^2
+  l.ly = h;                         // 2 Y Z
+  t.x = mul(a, sub(b, f));
+  t.y = sub(sqr(g), add(dbl(e2), e2));
+  t.z = mul(b, h);
+}
+
+// T <- T + Q (Q affine on the twist), returns the chord line coefficients.
+template <class C> GS_HD_NOINLINE void miller_add(Proj2<C>& t, Line<C>& l, const Aff<Fp2<C>>& q) {
+  Fp2<C> theta = sub(t.y, mul(q.y, t.z));
+  Fp2<C> lambda = sub(t.x, mul(q.x, t.z));
+  Fp2<C> c = sqr(theta);
+  Fp2<C> d = sqr(lambda);
+  Fp2<C> e = mul(lambda, d);
+  Fp2<C> f = mul(t.z, c);
+  Fp2<C> g = mul(t.x, d);
+  Fp2<C> h = sub(add(e, f), dbl(g));
+  l.l0 = sub(mul(theta, q.x), mul(lambda, q.y));
+  l.lx = neg(theta);
+  l.ly = lambda;
+  t.x = mul(lambda, h);
+  t.y = sub(mul(theta, sub(g, h)), mul(e, t.y));
+  t.z = mul(t.z, e);
+}
+
+// f *= line evaluated at P
+template <class C> GS_HD void miller_ell(Fp12<C>& f, const Line<C>& l, const Aff<Fq<C>>& p) {
+  Fp2<C> cx = mul_fp(l.lx, p.x), cy = mul_fp(l.ly, p.y);
+  if (C::TWIST_M)
+    f12_mul_by_014(f, l.l0, cx, cy);
+  else
+    f12_mul_by_034(f, cy, cx, l.l0);
+}
+
+// Multi-Miller loop over `np` pairs held in memory; pairs with an identity
+// argument are skipped (they contribute 1).  Result is NOT exponentiated.
+// `ts` is caller-provided scratch for the np running twist points.
+template <class C>
+GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts,
+                                 bool* live) {
+  f12_one(f);
+  bool any = false;
+  for (int k = 0; k < np; k++) {
+    live[k] = !(aff_is_inf(ps[k]) || aff_is_inf(qs[k]));
+    any |= live[k];
+    ts[k].x = qs[k].x;
+    ts[k].y = qs[k].y;
+    ts[k].z = one_of<Fp2<C>>();
+  }
+  if (!any) return;
+  Line<C> l;
+  for (int i = C::LOOP_LEN - 2; i >= 0; i--) {
+    f12_sqr(f, f);
+    for (int k = 0; k < np; k++) {
+      if (!live[k]) continue;
+      miller_dbl(ts[k], l);
+      miller_ell(f, l, ps[k]);
+    }
+    int d = C::LOOP[i];
+    if (d != 0) {
+      for (int k = 0; k < np; k++) {
+        if (!live[k]) continue;
+        Aff<Fp2<C>> q = qs[k];
+        if (d < 0) q.y = neg(q.y);
+        miller_add(ts[k], l, q);
+        miller_ell(f, l, ps[k]);
+      }
+    }
+  }
+  if (C::IS_BN) {
+    // two extra lines with pi(Q) and -pi^2(Q); twist Frobenius:
+    // pi(x', y') = (conj(x') * xi^((p-1)/3), conj(y') * xi^((p-1)/2))
+    for (int k = 0; k < np; k++) {
+      if (!live[k]) continue;
+      Aff<Fp2<C>> q1, q2;
+      q1.x = mul(conj(qs[k].x), frob_coeff<C>(1, 2));
+      q1.y = mul(conj(qs[k].y), frob_coeff<C>(1, 3));
+      q2.x = mul(qs[k].x, frob_coeff<C>(2, 2));
+      q2.y = neg(mul(qs[k].y, frob_coeff<C>(2, 3)));
+      miller_add(ts[k], l, q1);
+      miller_ell(f, l, ps[k]);
+      miller_add(ts[k], l, q2);
+      miller_ell(f, l, ps[k]);
+    }
+  }
+  if (C::LOOP_NEG) f12_conj(f, f);
+}
+
+// f^|x| by square-and-multiply over the 64-bit curve parameter, cyclotomic
+// squarings; then conjugate if x < 0 (so the result is f^x).
+template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f) {
+  Fp12<C> acc = f;
+  int top = 63;
+  while (!((C::X_ABS >> top) & 1)) top--;
+  for (int i = top - 1; i >= 0; i--) {
+    f12_cyclo_sqr(acc, acc);
+    if ((C::X_ABS >> i) & 1) f12_mul(acc, acc, f);
+  }
+  if (C::X_NEG) f12_conj(acc, acc);
+  r = acc;
+}
+
+// Final exponentiation, arkworks' exponent.  Returns false if f = 0.
+template <class C> GS_HD_NOINLINE void final_exp(Fp12<C>& out, const Fp12<C>& f) {
+  Fp12<C> r, t, y0, y1, y2;
+  // easy part: f^((p^6-1)(p^2+1))
+  f12_inv(t, f);
+  f12_conj(r, f);
+  f12_mul(r, r, t);
+  f12_frob(t, r, 2);
+  f12_mul(r, r, t);
+  if (!C::IS_BN) {
+    // hard part, eprint 2020/875 (Hayashida-Hayasaka-Teruya): exponent
+    // (x-1)^2 (x+p) (x^2+p^2-1) + 3
+    f12_cyclo_sqr(y0, r);       // r^2
+    f12_exp_by_x(y1, r);        // r^x
+    f12_conj(y2, r);            // r^-1
+    f12_mul(y1, y1, y2);        // r^(x-1)
+    f12_exp_by_x(y2, y1);       // r^(x(x-1))
+    f12_conj(y1, y1);           // r^-(x-1)
+    f12_mul(y1, y1, y2);        // r^((x-1)^2)
+    f12_exp_by_x(y2, y1);       // ^x
+    f12_frob(y1, y1, 1);        // ^p
+    f12_mul(y1, y1, y2);        // r^((x-1)^2 (x+p))
+    f12_mul(r, r, y0);          // r^3
+    f12_exp_by_x(y0, y1);       // ^x
+    f12_exp_by_x(y2, y0);       // ^x^2
+    f12_frob(y0, y1, 2);        // ^p^2
+    f12_conj(y1, y1);           // ^-1
+    f12_mul(y1, y1, y2);
+    f12_mul(y1, y1, y0);        // ^(x^2 + p^2 - 1)
+    f12_mul(out, r, y1);
+  } else {
+    // BN hard part (Fuentes-Castaneda et al.), as ark-ec models::bn [ark-mem].
+    // exp_by_neg_x(f) = f^(-x)
+    Fp12<C> y3, y4, y5, y6, y7, y8, y9;
+    f12_exp_by_x(y0, r);
+    f12_conj(y0, y0);           // r^-x
+    f12_cyclo_sqr(y1, y0);
+    f12_cyclo_sqr(y2, y1);
+    f12_mul(y3, y2, y1);
+    f12_exp_by_x(y4, y3);
+    f12_conj(y4, y4);
+    f12_cyclo_sqr(y5, y4);
+    f12_exp_by_x(y6, y5);
+    f12_conj(y6, y6);
+    f12_conj(y3, y3);
+    f12_conj(y6, y6);
+    f12_mul(y7, y6, y4);
+    f12_mul(y8, y7, y3);
+    f12_mul(y9, y8, y1);
+    f12_mul(t, y8, y4);         // y10
+    f12_mul(t, t, r);           // y11
+    f12_frob(y2, y9, 1);        // y12
+    f12_mul(y2, y2, t);         // y13
+    f12_frob(y8, y8, 2);
+    f12_mul(y2, y8, y2);        // y14
+    f12_conj(r, r);
+    f12_mul(y9, r, y9);         // y15
+    f12_frob(y9, y9, 3);
+    f12_mul(out, y9, y2);       // y16
+  }
+}
+
+}  // namespace gs

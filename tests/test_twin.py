@@ -1,0 +1,137 @@
+"""CPU twin of the HIP arithmetic headers vs the golden fixtures (no GPU).
+
+Validates the device ALGORITHMS (Montgomery CIOS, tower, Jacobian formulas,
+projective Miller loop, arkworks-exponent final exponentiation) by compiling
+the same .cuh sources for the host.  The GPU parity tests proper are in
+test_gpu_parity.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gsutil import HERE, REPO, curve, ptr
+
+TWIN_SRC = os.path.join(HERE, "twin", "host_twin.cpp")
+TWIN_SO = os.path.join(HERE, "twin", "libhost_twin.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="module")
+def twin():
+    srcs = [TWIN_SRC] + [
+        os.path.join(REPO, "groth_sahai_rs_amd", "csrc", f)
+        for f in os.listdir(os.path.join(REPO, "groth_sahai_rs_amd", "csrc"))
+        if f.endswith((".cuh", ".h"))
+    ]
+    if not os.path.exists(TWIN_SO) or any(os.path.getmtime(s) > os.path.getmtime(TWIN_SO) for s in srcs):
+        if not os.path.exists(CLANG):
+            pytest.skip("no host clang++ for the CPU twin")
+        subprocess.check_call([CLANG, "-O2", "-std=c++17", "-Wno-psabi", "-shared", "-fPIC", TWIN_SRC, "-o", TWIN_SO])
+    return ctypes.CDLL(TWIN_SO)
+
+
+CURVES = ["bls12_381", "bn254"]
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_field_ops(twin, cname):
+    c = curve(cname)
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        a = int.from_bytes(rng.bytes(48), "little") % c.p
+        b = int.from_bytes(rng.bytes(48), "little") % c.p
+        out = np.zeros(c.nq, dtype=np.uint64)
+        getattr(twin, "twin_fp_mul_" + cname)(ptr(c.fq(a)), ptr(c.fq(b)), ptr(out))
+        assert c.fq_dec(out) == a * b % c.p
+        out4 = np.zeros(4 * c.nq, dtype=np.uint64)
+        getattr(twin, "twin_fp_addsub_" + cname)(ptr(c.fq(a)), ptr(c.fq(b)), ptr(out4))
+        o = out4.reshape(4, c.nq)
+        assert c.fq_dec(o[0]) == (a + b) % c.p
+        assert c.fq_dec(o[1]) == (a - b) % c.p
+        assert c.fq_dec(o[2]) == (-a) % c.p
+        assert c.fq_dec(o[3]) == a * pow(2, -1, c.p) % c.p
+        x = int.from_bytes(rng.bytes(32), "little") % c.r
+        y = int.from_bytes(rng.bytes(32), "little") % c.r
+        outr = np.zeros(c.nr, dtype=np.uint64)
+        getattr(twin, "twin_fr_mul_" + cname)(ptr(c.fr(x)), ptr(c.fr(y)), ptr(outr))
+        assert c.fr_dec(outr) == x * y % c.r
+    for a in (1, 2, c.p - 1, 0x1234567):
+        out = np.zeros(c.nq, dtype=np.uint64)
+        getattr(twin, "twin_fp_inv_" + cname)(ptr(c.fq(a)), ptr(out))
+        assert c.fq_dec(out) == pow(a, -1, c.p)
+    # edge values: p-1 squared, zero
+    out = np.zeros(c.nq, dtype=np.uint64)
+    getattr(twin, "twin_fp_mul_" + cname)(ptr(c.fq(c.p - 1)), ptr(c.fq(c.p - 1)), ptr(out))
+    assert c.fq_dec(out) == 1
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_smul_golden(twin, cname):
+    c = curve(cname)
+    g = c.golden
+    g1 = c.g1(g["g1_smul"][0]["out"])  # k = 1 -> generator
+    g2 = c.g2(g["g2_smul"][0]["out"])
+    for e in g["g1_smul"]:
+        out = np.zeros(2 * c.nq, dtype=np.uint64)
+        getattr(twin, "twin_g1_smul_" + cname)(ptr(g1), ptr(c.fr_hex(e["k"])), ptr(out))
+        assert c.g1_dec(out) == e["out"], e["k"]
+    for e in g["g2_smul"]:
+        out = np.zeros(4 * c.nq, dtype=np.uint64)
+        getattr(twin, "twin_g2_smul_" + cname)(ptr(g2), ptr(c.fr_hex(e["k"])), ptr(out))
+        assert c.g2_dec(out) == e["out"], e["k"]
+    # k = 0 and identity base
+    out = np.ones(2 * c.nq, dtype=np.uint64)
+    getattr(twin, "twin_g1_smul_" + cname)(ptr(g1), ptr(c.fr(0)), ptr(out))
+    assert not out.any()
+    out = np.ones(2 * c.nq, dtype=np.uint64)
+    getattr(twin, "twin_g1_smul_" + cname)(ptr(c.g1(None)), ptr(c.fr(5)), ptr(out))
+    assert not out.any()
+    # P + (-P) = O, P + P = 2P through the generic add
+    two = c.g1(g["g1_smul"][1]["out"])
+    m1 = c.g1(g["g1_smul"][-1]["out"])  # (r-1) g = -g
+    out = np.ones(2 * c.nq, dtype=np.uint64)
+    getattr(twin, "twin_g1_add_" + cname)(ptr(g1), ptr(m1), ptr(out))
+    assert not out.any()
+    getattr(twin, "twin_g1_add_" + cname)(ptr(g1), ptr(g1), ptr(out))
+    assert (out == two).all()
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_fp12_golden(twin, cname):
+    c = curve(cname)
+    t = c.golden["fp12"]
+    a, b = c.f12(t["a"]), c.f12(t["b"])
+    f = getattr(twin, "twin_fp12_op_" + cname)
+    out = np.zeros(12 * c.nq, dtype=np.uint64)
+    for op, key in [(0, "mul"), (1, "sqr"), (2, "inv"), (3, "conj"), (4, "frob1"), (5, "frob2")]:
+        f(op, ptr(a), ptr(b), ptr(out))
+        assert c.f12_dec(out) == t[key], key
+    # a is a pairing value => in the cyclotomic subgroup: Granger-Scott == plain square
+    f(7, ptr(a), None, ptr(out))
+    assert c.f12_dec(out) == t["sqr"]
+    # frob3 = frob1(frob2)
+    tmp = np.zeros_like(out)
+    f(5, ptr(a), None, ptr(tmp))
+    f(4, ptr(tmp), None, ptr(out))
+    f(6, ptr(a), None, ptr(tmp))
+    assert (tmp == out).all()
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_pairing_golden(twin, cname):
+    c = curve(cname)
+    f = getattr(twin, "twin_multi_pairing_" + cname)
+    for e in c.golden["pairing"]:
+        out = np.zeros(12 * c.nq, dtype=np.uint64)
+        f(1, ptr(c.g1(e["p"])), ptr(c.g2(e["q"])), ptr(out), 1)
+        assert c.f12_dec(out) == e["out"]
+    # pairing_sum fixture: 4 cells, identity arguments skipped
+    ps = c.golden["pairing_sum"]
+    for cell, (ia, ib) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        P = np.concatenate([c.g1(x[ia]) for x in ps["x"]])
+        Q = np.concatenate([c.g2(y[ib]) for y in ps["y"]])
+        out = np.zeros(12 * c.nq, dtype=np.uint64)
+        f(len(ps["x"]), ptr(P), ptr(Q), ptr(out), 1)
+        assert c.f12_dec(out) == ps["out"][cell], cell
