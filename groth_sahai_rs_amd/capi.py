@@ -1,0 +1,226 @@
+"""ctypes binding of include/gs_amd.h.  Buffers are numpy arrays (host entry
+points) or torch CUDA tensors (``*_dev`` entry points, zero-copy via data_ptr)."""
+import ctypes
+import os
+
+import numpy as np
+
+GS_PPE, GS_MSMEG1, GS_MSMEG2, GS_QUAD = 0, 1, 2, 3
+CURVE_BLS12_381, CURVE_BN254 = 0, 1
+_ERR = {1: "GS_ERR_SHAPE", 2: "GS_ERR_DEVICE", 3: "GS_ERR_ARG", 4: "GS_ERR_NOCRS", 5: "GS_ERR_ALLOC"}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/gs_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "gs_ctx_create", "gs_ctx_destroy", "gs_set_stream", "gs_sync", "gs_last_error", "gs_version", "gs_sizes",
+    "gs_set_crs",
+    "gs_commit_g1_dev", "gs_commit_g2_dev", "gs_commit_fr_b1_dev", "gs_commit_fr_b2_dev",
+    "gs_commit_g1", "gs_commit_g2", "gs_commit_fr_b1", "gs_commit_fr_b2",
+    "gs_prove_batch_dev", "gs_prove_batch", "gs_verify_batch_dev", "gs_verify_batch",
+    "gs_verify_batch_rlc_dev", "gs_verify_batch_rlc", "gs_gt_finalize",
+    "gs_mat_left_mul_com1", "gs_mat_left_mul_com2", "gs_pairing_sum",
+    "gs_g1_mul_batch", "gs_g2_mul_batch", "gs_g1_mul_batch_dev", "gs_g2_mul_batch_dev",
+    "gs_multi_pairing_batch", "gs_multi_pairing_batch_dev", "gs_gt_pow_batch_dev",
+    "gs_prof_enable", "gs_prof_reset", "gs_prof_get",
+]
+
+
+class GsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (_ERR.get(code, "GS_ERR"), code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libgs_amd.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load the HIP extension; fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError(
+                "groth_sahai_rs_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p
+            )
+        _LIB = ctypes.CDLL(p)
+        _LIB.gs_last_error.restype = ctypes.c_char_p
+        _LIB.gs_version.restype = ctypes.c_char_p
+    return _LIB
+
+
+def _p(a):
+    """void* of a numpy array, torch tensor or None."""
+    if a is None:
+        return ctypes.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return ctypes.c_void_p(a.ctypes.data)
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    # torch tensor
+    assert a.is_contiguous()
+    return ctypes.c_void_p(a.data_ptr())
+
+
+class Engine:
+    """One gs_ctx: one GPU, one stream, one CRS."""
+
+    def __init__(self, curve=CURVE_BLS12_381, device=0):
+        self.lib = load_library()
+        self.curve = curve
+        self.ctx = ctypes.c_void_p()
+        rc = self.lib.gs_ctx_create(curve, device, ctypes.byref(self.ctx))
+        if rc != 0:
+            raise GsError(rc, "gs_ctx_create failed (no usable HIP device? there is no CPU fallback)")
+        sz = (ctypes.c_size_t * 6)()
+        self.lib.gs_sizes(curve, sz)
+        self.FQ, self.FR, self.G1, self.G2, self.GT, self.CRS = [int(x) for x in sz]
+        self.COM1, self.COM2 = 2 * self.G1, 2 * self.G2
+
+    def close(self):
+        if self.ctx:
+            self.lib.gs_ctx_destroy(self.ctx)
+            self.ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GsError(rc, (self.lib.gs_last_error(self.ctx) or b"").decode())
+
+    # -- context ------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.gs_set_stream(self.ctx, ctypes.c_void_p(stream_handle)))
+
+    def sync(self):
+        self._chk(self.lib.gs_sync(self.ctx))
+
+    def set_crs(self, crs):
+        crs = np.ascontiguousarray(crs).view(np.uint8).reshape(-1)
+        assert crs.size == self.CRS, (crs.size, self.CRS)
+        self._crs = crs
+        self._chk(self.lib.gs_set_crs(self.ctx, _p(crs)))
+
+    # -- shapes ---------------------------------------------------------------
+    def shape(self, ty):
+        xg, yg = ty in (GS_PPE, GS_MSMEG1), ty in (GS_PPE, GS_MSMEG2)
+        return dict(xg=xg, yg=yg, kx=2 if xg else 1, ky=2 if yg else 1, sx=self.G1 if xg else self.FR,
+                    sy=self.G2 if yg else self.FR,
+                    st={GS_PPE: self.GT, GS_MSMEG1: self.G1, GS_MSMEG2: self.G2, GS_QUAD: self.FR}[ty])
+
+    # -- host entry points (numpy uint8/uint64 arrays) --------------------------
+    def _out(self, nbytes):
+        return np.zeros(nbytes, dtype=np.uint8)
+
+    def commit(self, kind, vars_, rand):
+        fn = {"g1": self.lib.gs_commit_g1, "g2": self.lib.gs_commit_g2, "fr_b1": self.lib.gs_commit_fr_b1,
+              "fr_b2": self.lib.gs_commit_fr_b2}[kind]
+        vsz = {"g1": self.G1, "g2": self.G2, "fr_b1": self.FR, "fr_b2": self.FR}[kind]
+        osz = self.COM1 if kind in ("g1", "fr_b1") else self.COM2
+        v = np.ascontiguousarray(vars_).view(np.uint8).reshape(-1)
+        r = np.ascontiguousarray(rand).view(np.uint8).reshape(-1)
+        n = v.size // vsz
+        out = self._out(n * osz)
+        self._chk(fn(self.ctx, ctypes.c_size_t(n), _p(v), _p(r), _p(out)))
+        return out.reshape(n, osz)
+
+    def prove_batch(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, want_coms=True):
+        sh = self.shape(ty)
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        xc = self._out(N * m * self.COM1) if want_coms else None
+        yc = self._out(N * n * self.COM2) if want_coms else None
+        pi = self._out(N * sh["kx"] * self.COM2)
+        th = self._out(N * sh["ky"] * self.COM1)
+        self._chk(self.lib.gs_prove_batch(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(X)), _p(u8(Y)), _p(u8(A)),
+                                          _p(u8(B)), _p(u8(Gamma)), _p(u8(R)), _p(u8(S)), _p(u8(T)), _p(xc), _p(yc),
+                                          _p(pi), _p(th)))
+        return dict(xcoms=xc, ycoms=yc, pi=pi, theta=th)
+
+    def verify_batch(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta):
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        ok = np.zeros(N, dtype=np.uint8)
+        self._chk(self.lib.gs_verify_batch(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(A)), _p(u8(B)),
+                                           _p(u8(Gamma)), _p(u8(target)), _p(u8(xcoms)), _p(u8(ycoms)), _p(u8(pi)),
+                                           _p(u8(theta)), _p(ok)))
+        return ok
+
+    def mat_left_mul(self, group, rows, k, lhs, col):
+        fn = self.lib.gs_mat_left_mul_com1 if group == 1 else self.lib.gs_mat_left_mul_com2
+        osz = self.COM1 if group == 1 else self.COM2
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        out = self._out(rows * osz)
+        self._chk(fn(self.ctx, rows, k, _p(u8(lhs)), _p(u8(col)), _p(out)))
+        return out.reshape(rows, osz)
+
+    def pairing_sum(self, k, x, y):
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        out = self._out(4 * self.GT)
+        self._chk(self.lib.gs_pairing_sum(self.ctx, k, _p(u8(x)), _p(u8(y)), _p(out)))
+        return out.reshape(4, self.GT)
+
+    def g_mul_batch(self, group, points, scalars, broadcast=False):
+        fn = self.lib.gs_g1_mul_batch if group == 1 else self.lib.gs_g2_mul_batch
+        gsz = self.G1 if group == 1 else self.G2
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        k = u8(scalars)
+        n = k.size // self.FR
+        out = self._out(n * gsz)
+        self._chk(fn(self.ctx, ctypes.c_size_t(n), _p(u8(points)), 1 if broadcast else 0, _p(k), _p(out)))
+        return out.reshape(n, gsz)
+
+    def multi_pairing_batch(self, n, k, P, Q):
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        out = self._out(n * self.GT)
+        self._chk(self.lib.gs_multi_pairing_batch(self.ctx, ctypes.c_size_t(n), k, _p(u8(P)), _p(u8(Q)), _p(out)))
+        return out.reshape(n, self.GT)
+
+    # -- device entry points (torch CUDA uint8 tensors; asynchronous) --------------
+    def prove_batch_dev(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, xcoms, ycoms, pi, theta):
+        self._chk(self.lib.gs_prove_batch_dev(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(X), _p(Y), _p(A), _p(B),
+                                              _p(Gamma), _p(R), _p(S), _p(T), _p(xcoms), _p(ycoms), _p(pi),
+                                              _p(theta)))
+
+    def verify_batch_dev(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, ok):
+        self._chk(self.lib.gs_verify_batch_dev(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(A), _p(B), _p(Gamma),
+                                               _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(ok)))
+
+    def g_mul_batch_dev(self, group, n, points, broadcast, scalars, out):
+        fn = self.lib.gs_g1_mul_batch_dev if group == 1 else self.lib.gs_g2_mul_batch_dev
+        self._chk(fn(self.ctx, ctypes.c_size_t(n), _p(points), 1 if broadcast else 0, _p(scalars), _p(out)))
+
+    def multi_pairing_batch_dev(self, n, k, P, Q, out):
+        self._chk(self.lib.gs_multi_pairing_batch_dev(self.ctx, ctypes.c_size_t(n), k, _p(P), _p(Q), _p(out)))
+
+    def gt_pow_batch_dev(self, n, base, k, out):
+        self._chk(self.lib.gs_gt_pow_batch_dev(self.ctx, ctypes.c_size_t(n), _p(base), _p(k), _p(out)))
+
+    # -- profiling hook ---------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self.lib.gs_prof_enable(self.ctx, 1 if on else 0)
+
+    def prof_reset(self):
+        self.lib.gs_prof_reset(self.ctx)
+
+    def prof_get(self):
+        out = []
+        i = 0
+        while True:
+            name = ctypes.create_string_buffer(128)
+            ms = ctypes.c_double()
+            n = ctypes.c_uint64()
+            if self.lib.gs_prof_get(self.ctx, i, name, ctypes.c_size_t(128), ctypes.byref(ms), ctypes.byref(n)) != 0:
+                break
+            out.append((name.value.decode(), ms.value, n.value))
+            i += 1
+        return out

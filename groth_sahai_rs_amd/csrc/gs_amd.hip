@@ -1,0 +1,1006 @@
+// Host side of the C ABI declared in include/gs_amd.h: context, CRS tables,
+// per-shape task tables ("plans"), kernel launches.  No CPU fallback: every
+// compute entry point needs a working HIP device.
+#include "../../include/gs_amd.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gs_params_bls12_381.h"
+#include "gs_params_bn254.h"
+#include "gs_kernels.cuh"
+
+namespace gs {
+GS_ZERO_ONE(Bls12_381)
+GS_ZERO_ONE(Bn254)
+}  // namespace gs
+using namespace gs;
+
+#define GS_VERSION "gs-amd 0.1 (gfx950)"
+
+// ---------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+struct ProfEntry {
+  double ms = 0;
+  uint64_t n = 0;
+};
+
+struct gs_ctx {
+  int curve = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool have_crs = false;
+  std::string err;
+  // CRS-derived device data
+  DevBuf crs_g1;   // 6 G1 points: u0.0 u0.1 u1.0 u1.1 W1.0 W1.1
+  DevBuf crs_g2;   // 6 G2 points: v0.0 v0.1 v1.0 v1.1 W2.0 W2.1
+  DevBuf tab_g1;   // 5 window tables (u0.0 u0.1 u1.0 u1.1 W1.1)
+  DevBuf tab_g2;
+  // scratch
+  std::map<std::string, DevBuf> scratch;
+  // profiling
+  bool prof = false;
+  std::map<std::string, ProfEntry> prof_map;
+  std::vector<std::string> prof_order;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+#define HIPCHK(ctx, call)                                          \
+  do {                                                             \
+    hipError_t e_ = (call);                                        \
+    if (e_ != hipSuccess) return fail(ctx, GS_ERR_DEVICE, #call, e_); \
+  } while (0)
+
+static int ensure(gs_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return GS_OK;
+  if (b.p) hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes < 256 ? 256 : bytes;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) return fail(c, GS_ERR_ALLOC, "hipMalloc", e);
+  b.cap = want;
+  return GS_OK;
+}
+static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
+  DevBuf& b = c->scratch[name];
+  int rc = ensure(c, b, bytes);
+  *out = b.p;
+  return rc;
+}
+
+// launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
+template <class K, class... Args>
+static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, Args... args) {
+  if (total == 0) return GS_OK;
+  unsigned grid = (unsigned)((total + block - 1) / block);
+  if (c->prof) hipEventRecord(c->ev0, c->stream);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, c->stream, args...);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, GS_ERR_DEVICE, name, e);
+  if (c->prof) {
+    hipEventRecord(c->ev1, c->stream);
+    hipEventSynchronize(c->ev1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (!c->prof_map.count(name)) c->prof_order.push_back(name);
+    ProfEntry& p = c->prof_map[name];
+    p.ms += ms;
+    p.n += 1;
+  }
+  return GS_OK;
+}
+#define RC(x)                 \
+  do {                        \
+    int rc_ = (x);            \
+    if (rc_ != GS_OK) return rc_; \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// shape helpers
+// ---------------------------------------------------------------------------
+static inline bool x_is_group(int ty) { return ty == GS_PPE || ty == GS_MSMEG1; }
+static inline bool y_is_group(int ty) { return ty == GS_PPE || ty == GS_MSMEG2; }
+
+template <class C> struct Sz {
+  static constexpr size_t FQ = sizeof(Fq<C>), FR = sizeof(Fr<C>), G1 = 2 * FQ, G2 = 4 * FQ, GT = 12 * FQ,
+                          COM1 = 2 * G1, COM2 = 2 * G2, CRS = 2 * COM1 + 2 * COM2 + G1 + G2 + GT;
+};
+
+// table ids inside tab_g1/tab_g2: 0 u0.0, 1 u0.1, 2 u1.0, 3 u1.1, 4 W.1 ; W.0 aliases u1.0
+static inline uint8_t tb_u(int k, int c) { return (uint8_t)(2 * k + c); }
+static inline uint8_t tb_w(int c) { return c ? 4 : 2; }
+
+// Task tables are immutable once uploaded: they are cached per (name, content
+// hash) so that a later batch never overwrites a table an in-flight kernel reads.
+template <class T> static int upload(gs_ctx* c, const char* name, const std::vector<T>& v, const T** out) {
+  uint64_t h = 1469598103934665603ull;
+  const uint8_t* b = (const uint8_t*)v.data();
+  for (size_t i = 0; i < v.size() * sizeof(T); i++) h = (h ^ b[i]) * 1099511628211ull;
+  char key[160];
+  snprintf(key, sizeof key, "plan%s.%zu.%016llx", name, v.size(), (unsigned long long)h);
+  bool fresh = !c->scratch.count(key);
+  void* p;
+  RC(scratch(c, key, v.size() * sizeof(T) + 16, &p));
+  if (fresh && !v.empty()) HIPCHK(c, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return GS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one side (G1 or G2) of commit / prove expressed as engine tasks
+// ---------------------------------------------------------------------------
+struct SidePlan {
+  std::vector<VarTask> var;
+  std::vector<FixTask> fix;
+  std::vector<RedTask> red;
+  int nslots = 0;
+};
+
+static FixTask mkfix(int s0, int t0, int s1, int t1, int a_arr, int a_idx, int slot, int a_neg = 0) {
+  FixTask f;
+  f.s0 = (uint16_t)s0;
+  f.s1 = (uint16_t)s1;
+  f.t0 = (uint8_t)t0;
+  f.t1 = (uint8_t)t1;
+  f.a_arr = (uint8_t)a_arr;
+  f.a_idx = (uint16_t)a_idx;
+  f.a_neg = (uint8_t)a_neg;
+  f.slot = (uint16_t)slot;
+  return f;
+}
+static VarTask mkvar(int s, int arr, int idx, int slot) {
+  VarTask v;
+  v.s_idx = (uint16_t)s;
+  v.p_arr = (uint8_t)arr;
+  v.p_idx = (uint16_t)idx;
+  v.slot = (uint16_t)slot;
+  v.pad = 0;
+  return v;
+}
+static RedTask mkred(int b0, int e0, int b1, int e1, int out_arr, int out_idx) {
+  RedTask r;
+  r.b0 = (uint16_t)b0;
+  r.e0 = (uint16_t)e0;
+  r.b1 = (uint16_t)b1;
+  r.e1 = (uint16_t)e1;
+  r.out_arr = (uint8_t)out_arr;
+  r.out_idx = (uint16_t)out_idx;
+  r.pad = 0;
+  return r;
+}
+
+// Build the plan of one side.
+//  nv      committed variables on this side (m for the G1 side, n for the G2 side)
+//  nc      constants paired with the OTHER side's variables that live here (len of A for G1 side = n; B for G2 = m)
+//  group   variables on this side are group elements (else scalars)
+//  kc      columns of this side's commit randomness (2 group / 1 scalar)
+//  npf     number of proof elements on this side (theta count = ky for G1 side, pi count = kx for G2 side)
+//  offsets into the pool: rc (nv x kc commit randomness), vc (scalar variables), cs (nc x npf scalars multiplying
+//  the constants: SC for the G1 side / RC for the G2 side, indexed [j*npf + l]), ph (npf x nv: PHI / PSI),
+//  f0 (npf x kc fixed scalars: TC for G1 side, OM for G2 side), sg (npf: SIG / RHO)
+//  arrays: 0 = variables (group), 1 = constants (group)
+static void build_side(SidePlan& sp, bool want_coms, int nv, int nc, bool group, int kc, int npf, int rc, int vc,
+                       int cs, int ph, int f0, int sg) {
+  int slot = 0;
+  if (want_coms) {
+    for (int i = 0; i < nv; i++) {
+      int s_begin = slot;
+      for (int c = 0; c < 2; c++) {
+        if (group)
+          sp.fix.push_back(mkfix(rc + 2 * i, tb_u(0, c), rc + 2 * i + 1, tb_u(1, c), c ? 0 : 0xFF, i, slot++));
+        else
+          sp.fix.push_back(mkfix(vc + i, tb_w(c), rc + i, tb_u(0, c), 0xFF, 0, slot++));
+      }
+      sp.red.push_back(mkred(s_begin, s_begin + 1, s_begin + 1, s_begin + 2, 0, i));
+    }
+  }
+  for (int l = 0; l < npf; l++) {
+    int b0 = slot;
+    if (group) {
+      sp.fix.push_back(mkfix(f0 + l * 2, tb_u(0, 0), f0 + l * 2 + 1, tb_u(1, 0), 0xFF, 0, slot++));
+      int b1 = slot;
+      sp.fix.push_back(mkfix(f0 + l * 2, tb_u(0, 1), f0 + l * 2 + 1, tb_u(1, 1), 0xFF, 0, slot++));
+      for (int j = 0; j < nc; j++) sp.var.push_back(mkvar(cs + j * npf + l, 1, j, slot++));
+      for (int i = 0; i < nv; i++) sp.var.push_back(mkvar(ph + l * nv + i, 0, i, slot++));
+      sp.red.push_back(mkred(b0, b1, b1, slot, 1, l));
+    } else {
+      sp.fix.push_back(mkfix(sg + l, tb_w(0), f0 + l, tb_u(0, 0), 0xFF, 0, slot++));
+      int b1 = slot;
+      sp.fix.push_back(mkfix(sg + l, tb_w(1), f0 + l, tb_u(0, 1), 0xFF, 0, slot++));
+      sp.red.push_back(mkred(b0, b1, b1, slot, 1, l));
+    }
+  }
+  sp.nslots = slot;
+}
+
+template <class C, class F>
+static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
+                    int pool_n, const Aff<F>* tab, const OutTab& outs) {
+  std::string t(tag);
+  const VarTask* dvar;
+  const FixTask* dfix;
+  const RedTask* dred;
+  RC(upload(c, (t + ".var").c_str(), sp.var, &dvar));
+  RC(upload(c, (t + ".fix").c_str(), sp.fix, &dfix));
+  RC(upload(c, (t + ".red").c_str(), sp.red, &dred));
+  void* part;
+  RC(scratch(c, (t + ".part").c_str(), N * sp.nslots * sizeof(Jac<F>), &part));
+  RC(launch(c, (std::string("k_fix") + tag).c_str(), k_fix<C, F>, N * sp.fix.size(), 64, N * sp.fix.size(),
+            (int)sp.fix.size(), dfix, arrs, pool, pool_n, tab, (Jac<F>*)part, sp.nslots));
+  RC(launch(c, (std::string("k_var") + tag).c_str(), k_var<C, F>, N * sp.var.size(), 64, N * sp.var.size(),
+            (int)sp.var.size(), dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
+  RC(launch(c, (std::string("k_red") + tag).c_str(), k_red<C, F>, N * sp.red.size(), 64, N * sp.red.size(),
+            (int)sp.red.size(), dred, (const Jac<F>*)part, sp.nslots, outs));
+  return GS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-curve implementation
+// ---------------------------------------------------------------------------
+template <class C> struct Impl {
+  typedef Fq<C> F1;
+  typedef Fp2<C> F2;
+  typedef Aff<F1> A1;
+  typedef Aff<F2> A2;
+  typedef Fr<C> S;
+  typedef Fp12<C> GT;
+  typedef Sz<C> Z;
+
+  static int set_crs(gs_ctx* c, const void* crs_host) {
+    const uint8_t* h = (const uint8_t*)crs_host;
+    A1 g1pts[6];
+    A2 g2pts[6];
+    memcpy(&g1pts[0], h, 4 * sizeof(A1));                     // u0.0 u0.1 u1.0 u1.1
+    memcpy(&g2pts[0], h + 2 * Z::COM1, 4 * sizeof(A2));       // v0.0 v0.1 v1.0 v1.1
+    A1 g1;
+    A2 g2;
+    memcpy(&g1, h + 2 * Z::COM1 + 2 * Z::COM2, sizeof g1);
+    memcpy(&g2, h + 2 * Z::COM1 + 2 * Z::COM2 + Z::G1, sizeof g2);
+    // W1 = u[1] + (O, g1), W2 = v[1] + (O, g2)   (data_structures.rs:323-326, 368-371), derived on the device
+    g1pts[4] = g1pts[2];
+    g2pts[4] = g2pts[2];
+    g1pts[5] = g1;   // slot 5 holds the addend on the way in
+    g2pts[5] = g2;
+    RC(ensure(c, c->crs_g1, sizeof g1pts));
+    RC(ensure(c, c->crs_g2, sizeof g2pts));
+    HIPCHK(c, hipMemcpy(c->crs_g1.p, g1pts, sizeof g1pts, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->crs_g2.p, g2pts, sizeof g2pts, hipMemcpyHostToDevice));
+    RC(launch(c, "k_crs_derive.g1", k_crs_derive<C, F1>, 1, 64, (A1*)c->crs_g1.p));
+    RC(launch(c, "k_crs_derive.g2", k_crs_derive<C, F2>, 1, 64, (A2*)c->crs_g2.p));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(g1pts, c->crs_g1.p, sizeof g1pts, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g2pts, c->crs_g2.p, sizeof g2pts, hipMemcpyDeviceToHost));
+    // window tables for bases {u0.0,u0.1,u1.0,u1.1,W.1}
+    A1 b1[5] = {g1pts[0], g1pts[1], g1pts[2], g1pts[3], g1pts[5]};
+    A2 b2[5] = {g2pts[0], g2pts[1], g2pts[2], g2pts[3], g2pts[5]};
+    void *db1, *db2;
+    RC(scratch(c, "crs.b1", sizeof b1, &db1));
+    RC(scratch(c, "crs.b2", sizeof b2, &db2));
+    HIPCHK(c, hipMemcpy(db1, b1, sizeof b1, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db2, b2, sizeof b2, hipMemcpyHostToDevice));
+    size_t ne = (size_t)5 * 32 * 256;
+    RC(ensure(c, c->tab_g1, ne * sizeof(A1)));
+    RC(ensure(c, c->tab_g2, ne * sizeof(A2)));
+    RC(launch(c, "k_build_tables.g1", k_build_tables<C, F1>, ne, 64, 5, (const A1*)db1, (A1*)c->tab_g1.p));
+    RC(launch(c, "k_build_tables.g2", k_build_tables<C, F2>, ne, 64, 5, (const A2*)db2, (A2*)c->tab_g2.p));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_crs = true;
+    return GS_OK;
+  }
+
+  static PoolMap prove_pool(int m, int n, int kx, int ky) {
+    PoolMap pm;
+    memset(&pm, 0, sizeof pm);
+    int o = 0;
+    pm.RC = o; o += m * kx;
+    pm.SC = o; o += n * ky;
+    pm.PSI = o; o += kx * n;
+    pm.PHI = o; o += ky * m;
+    pm.OM = o; o += kx * ky;
+    pm.TC = o; o += ky * kx;
+    pm.RHO = o; o += kx;
+    pm.SIG = o; o += ky;
+    pm.XC = o; o += m;
+    pm.YC = o; o += n;
+    pm.total = o;
+    return pm;
+  }
+
+  // prove / commit_and_prove for all four types (prove.rs:71-489)
+  static int prove(gs_ctx* c, int ty, size_t N, int m, int n, const void* X, const void* Y, const void* A,
+                   const void* B, const void* G, const void* R, const void* Sm, const void* T, void* xcoms,
+                   void* ycoms, void* pi, void* theta) {
+    bool xg = x_is_group(ty), yg = y_is_group(ty);
+    int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+    PoolMap pm = prove_pool(m, n, kx, ky);
+    void* pool;
+    RC(scratch(c, "prove.pool", N * pm.total * sizeof(S), &pool));
+    RC(launch(c, "k_prep_prove", k_prep_prove<C>, N, 64, N, m, n, kx, ky, (const S*)G, (const S*)R, (const S*)Sm,
+              (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
+              yg ? nullptr : (const S*)B, pm, (S*)pool));
+    // G1 side: xcoms (m) + theta (ky).  constants A (len n) multiply S; Phi multiplies X; fixed part T.
+    {
+      SidePlan sp;
+      build_side(sp, xcoms != nullptr, m, n, xg, kx, ky, pm.RC, pm.XC, pm.SC, pm.PHI, pm.TC, pm.SIG);
+      ArrTab arrs;
+      memset(&arrs, 0, sizeof arrs);
+      if (xg) {
+        arrs.base[0] = (const uint8_t*)X;
+        arrs.stride[0] = (uint32_t)(m * sizeof(A1));
+        arrs.base[1] = (const uint8_t*)A;
+        arrs.stride[1] = (uint32_t)(n * sizeof(A1));
+      }
+      OutTab outs;
+      memset(&outs, 0, sizeof outs);
+      outs.base[0] = (uint8_t*)xcoms;
+      outs.stride[0] = (uint32_t)(m * Z::COM1);
+      outs.base[1] = (uint8_t*)theta;
+      outs.stride[1] = (uint32_t)(ky * Z::COM1);
+      RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs)));
+    }
+    // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
+    {
+      SidePlan sp;
+      build_side(sp, ycoms != nullptr, n, m, yg, ky, kx, pm.SC, pm.YC, pm.RC, pm.PSI, pm.OM, pm.RHO);
+      ArrTab arrs;
+      memset(&arrs, 0, sizeof arrs);
+      if (yg) {
+        arrs.base[0] = (const uint8_t*)Y;
+        arrs.stride[0] = (uint32_t)(n * sizeof(A2));
+        arrs.base[1] = (const uint8_t*)B;
+        arrs.stride[1] = (uint32_t)(m * sizeof(A2));
+      }
+      OutTab outs;
+      memset(&outs, 0, sizeof outs);
+      outs.base[0] = (uint8_t*)ycoms;
+      outs.stride[0] = (uint32_t)(n * Z::COM2);
+      outs.base[1] = (uint8_t*)pi;
+      outs.stride[1] = (uint32_t)(kx * Z::COM2);
+      RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tab_g2.p, outs)));
+    }
+    return GS_OK;
+  }
+
+  // commitments only (commit.rs:59-256): a "prove" side with no proof elements
+  template <class F>
+  static int commit(gs_ctx* c, size_t count, bool group, const void* vars, const void* rand, void* out,
+                    const Aff<F>* tab, const char* tag) {
+    int kc = group ? 2 : 1;
+    PoolMap pm;
+    memset(&pm, 0, sizeof pm);
+    pm.RC = 0;
+    pm.XC = kc;
+    pm.total = kc + 1;
+    void* pool;
+    RC(scratch(c, "commit.pool", count * pm.total * sizeof(S), &pool));
+    // reuse k_prep_prove with m = 1 variable per "equation", no Gamma work (n = 0, ky = 0)
+    RC(launch(c, "k_prep_commit", k_prep_prove<C>, count, 64, count, 1, 0, kc, 0, (const S*)nullptr, (const S*)rand,
+              (const S*)nullptr, (const S*)nullptr, group ? nullptr : (const S*)vars, (const S*)nullptr,
+              (const S*)nullptr, (const S*)nullptr, pm, (S*)pool));
+    SidePlan sp;
+    build_side(sp, true, 1, 0, group, kc, 0, pm.RC, pm.XC, 0, 0, 0, 0);
+    ArrTab arrs;
+    memset(&arrs, 0, sizeof arrs);
+    if (group) {
+      arrs.base[0] = (const uint8_t*)vars;
+      arrs.stride[0] = (uint32_t)sizeof(Aff<F>);
+    }
+    OutTab outs;
+    memset(&outs, 0, sizeof outs);
+    outs.base[0] = (uint8_t*)out;
+    outs.stride[0] = (uint32_t)(2 * sizeof(Aff<F>));
+    return run_side<C, F>(c, tag, count, sp, arrs, (const S*)pool, pm.total, tab, outs);
+  }
+
+  // --------------------------------------------------------------- verify --
+  struct VerifyPlan {
+    SidePlan g1;                      // PA_j (j<n) [+ PB] as Com1-shaped pairs
+    std::vector<MillerTask> mt;       // ordered by cell
+    int cb[5];
+    int npa;                          // Com1 elements in the PA scratch per equation
+  };
+
+  static void add_pair(std::vector<PairRef>& v, int p_arr, int p_idx, int neg, int q_arr, int q_idx) {
+    PairRef r;
+    r.p_arr = (uint8_t)p_arr;
+    r.p_idx = (uint16_t)p_idx;
+    r.neg = (uint8_t)neg;
+    r.q_arr = (uint8_t)q_arr;
+    r.q_idx = (uint16_t)q_idx;
+    r.pad = 0;
+    v.push_back(r);
+  }
+
+  // P arrays: 0 PA scratch, 1 xcoms, 2 crs G1 consts, 3 theta
+  // Q arrays: 0 ycoms, 1 B, 2 crs G2 consts, 3 pi, 4 target (MSMEG2)
+  static void build_verify(VerifyPlan& vp, int ty, int m, int n, const PoolMap& pm) {
+    bool xg = x_is_group(ty), yg = y_is_group(ty);
+    int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+    // ---- G1-side points: PA_j.a = map_a_j.a + sum_i Gamma_ij c_i.a ;  PB.a = sum_i b_i c_i.a - lin_t
+    // engine arrays: 0 = xcoms as 2m G1 points, 1 = A (group), 2 = target (MSMEG1)
+    SidePlan& sp = vp.g1;
+    int slot = 0;
+    for (int j = 0; j < n; j++) {
+      int b[2], e[2];
+      for (int a = 0; a < 2; a++) {
+        b[a] = slot;
+        if (xg) {
+          if (a == 1) sp.fix.push_back(mkfix(0, 0xFF, 0, 0xFF, 1, j, slot++));
+        } else {
+          sp.fix.push_back(mkfix(pm.AC + j, tb_w(a), 0, 0xFF, 0xFF, 0, slot++));
+        }
+        for (int i = 0; i < m; i++) sp.var.push_back(mkvar(pm.GC + i * n + j, 0, 2 * i + a, slot++));
+        e[a] = slot;
+      }
+      sp.red.push_back(mkred(b[0], e[0], b[1], e[1], 0, j));
+    }
+    vp.npa = n;
+    if (!yg) {
+      int b[2], e[2];
+      for (int a = 0; a < 2; a++) {
+        b[a] = slot;
+        for (int i = 0; i < m; i++) sp.var.push_back(mkvar(pm.BC + i, 0, 2 * i + a, slot++));
+        if (ty == GS_MSMEG1 && a == 1) sp.fix.push_back(mkfix(0, 0xFF, 0, 0xFF, 2, 0, slot++, 1));  // - t
+        if (ty == GS_QUAD) sp.fix.push_back(mkfix(pm.NT, tb_w(a), 0, 0xFF, 0xFF, 0, slot++));       // (-t) W1.a
+        e[a] = slot;
+      }
+      sp.red.push_back(mkred(b[0], e[0], b[1], e[1], 0, n));
+      vp.npa = n + 1;
+    }
+    sp.nslots = slot;
+    // ---- Miller tasks per cell
+    vp.mt.clear();
+    for (int cell = 0; cell < 4; cell++) {
+      int a = cell >> 1, b = cell & 1;
+      std::vector<PairRef> pr;
+      for (int j = 0; j < n; j++) add_pair(pr, 0, 2 * j + a, 0, 0, 2 * j + b);
+      if (yg) {
+        if (b == 1)
+          for (int i = 0; i < m; i++) add_pair(pr, 1, 2 * i + a, 0, 1, i);
+      } else {
+        add_pair(pr, 0, 2 * n + a, 0, 2, 4 + b);  // (PB.a, W2.b)
+      }
+      for (int k = 0; k < kx; k++) add_pair(pr, 2, 2 * k + a, 1, 3, 2 * k + b);   // (-u_k.a, pi_k.b)
+      for (int l = 0; l < ky; l++) add_pair(pr, 3, 2 * l + a, 1, 2, 2 * l + b);   // (-theta_l.a, v_l.b)
+      if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 2, 4 + a, 1, 4, 0);              // (-W1.a, t)
+      vp.cb[cell] = (int)vp.mt.size();
+      for (size_t s = 0; s < pr.size(); s += MILLER_CH) {
+        MillerTask t;
+        memset(&t, 0, sizeof t);
+        t.cell = (uint8_t)cell;
+        t.np = (uint8_t)((pr.size() - s) < (size_t)MILLER_CH ? (pr.size() - s) : MILLER_CH);
+        for (int q = 0; q < t.np; q++) t.pr[q] = pr[s + q];
+        vp.mt.push_back(t);
+      }
+    }
+    vp.cb[4] = (int)vp.mt.size();
+  }
+
+  static int verify(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                    const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                    uint8_t* ok) {
+    bool xg = x_is_group(ty), yg = y_is_group(ty);
+    int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+    PoolMap pm;
+    memset(&pm, 0, sizeof pm);
+    int o = 0;
+    pm.GC = o; o += m * n;
+    pm.AC = o; o += n;
+    pm.BC = o; o += m;
+    pm.NT = o; o += 1;
+    pm.total = o;
+    void* pool;
+    RC(scratch(c, "verify.pool", N * pm.total * sizeof(S), &pool));
+    RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, (const S*)G, xg ? nullptr : (const S*)A,
+              yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm, (S*)pool));
+    VerifyPlan vp;
+    build_verify(vp, ty, m, n, pm);
+    // G1-side points
+    void* pa;
+    RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
+    {
+      ArrTab arrs;
+      memset(&arrs, 0, sizeof arrs);
+      arrs.base[0] = (const uint8_t*)xcoms;
+      arrs.stride[0] = (uint32_t)(m * Z::COM1);
+      if (xg) {
+        arrs.base[1] = (const uint8_t*)A;
+        arrs.stride[1] = (uint32_t)(n * sizeof(A1));
+      }
+      if (ty == GS_MSMEG1) {
+        arrs.base[2] = (const uint8_t*)target;
+        arrs.stride[2] = (uint32_t)sizeof(A1);
+      }
+      OutTab outs;
+      memset(&outs, 0, sizeof outs);
+      outs.base[0] = (uint8_t*)pa;
+      outs.stride[0] = (uint32_t)(vp.npa * Z::COM1);
+      RC((run_side<C, F1>(c, ".vg1", N, vp.g1, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs)));
+    }
+    // Miller
+    const MillerTask* dmt;
+    RC(upload(c, "verify.mt", vp.mt, &dmt));
+    int ntask = (int)vp.mt.size();
+    void* mpart;
+    RC(scratch(c, "verify.mpart", N * ntask * sizeof(GT), &mpart));
+    ArrTab parr, qarr;
+    memset(&parr, 0, sizeof parr);
+    memset(&qarr, 0, sizeof qarr);
+    parr.base[0] = (const uint8_t*)pa;
+    parr.stride[0] = (uint32_t)(vp.npa * Z::COM1);
+    parr.base[1] = (const uint8_t*)xcoms;
+    parr.stride[1] = (uint32_t)(m * Z::COM1);
+    parr.base[2] = (const uint8_t*)c->crs_g1.p;
+    parr.stride[2] = 0;
+    parr.base[3] = (const uint8_t*)theta;
+    parr.stride[3] = (uint32_t)(ky * Z::COM1);
+    qarr.base[0] = (const uint8_t*)ycoms;
+    qarr.stride[0] = (uint32_t)(n * Z::COM2);
+    qarr.base[1] = (const uint8_t*)B;
+    qarr.stride[1] = (uint32_t)(m * sizeof(A2));
+    qarr.base[2] = (const uint8_t*)c->crs_g2.p;
+    qarr.stride[2] = 0;
+    qarr.base[3] = (const uint8_t*)pi;
+    qarr.stride[3] = (uint32_t)(kx * Z::COM2);
+    qarr.base[4] = (const uint8_t*)target;
+    qarr.stride[4] = (uint32_t)sizeof(A2);
+    RC(launch(c, "k_miller", k_miller<C>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
+    void* cellok;
+    RC(scratch(c, "verify.cellok", N * 4, &cellok));
+    RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cb[0], vp.cb[1], vp.cb[2], vp.cb[3], vp.cb[4],
+              (const GT*)mpart, ty == GS_PPE ? (const GT*)target : nullptr, (uint8_t*)cellok));
+    RC(launch(c, "k_and4", k_and4, N, 256, N, (const uint8_t*)cellok, ok));
+    return GS_OK;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// dispatch helpers
+// ---------------------------------------------------------------------------
+#define DISPATCH(ctx, EXPR)                                   \
+  ((ctx)->curve == GS_CURVE_BLS12_381 ? Impl<Bls12_381>::EXPR : Impl<Bn254>::EXPR)
+
+static size_t sz_fq(int curve) { return curve == 0 ? sizeof(Fq<Bls12_381>) : sizeof(Fq<Bn254>); }
+static const size_t SZ_FR = 32;
+
+struct HostStage {  // host<->device staging for the un-suffixed entry points
+  gs_ctx* c;
+  std::vector<void*> bufs;
+  explicit HostStage(gs_ctx* ctx) : c(ctx) {}
+  ~HostStage() {
+    for (void* p : bufs) hipFree(p);
+  }
+  int in(const void* h, size_t bytes, void** d) {
+    *d = nullptr;
+    if (!h || bytes == 0) return GS_OK;
+    hipError_t e = hipMalloc(d, bytes);
+    if (e != hipSuccess) return fail(c, GS_ERR_ALLOC, "hipMalloc(stage)", e);
+    bufs.push_back(*d);
+    e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(c, GS_ERR_DEVICE, "hipMemcpy H2D", e);
+    return GS_OK;
+  }
+  int out(void* h, size_t bytes, void** d) {
+    *d = nullptr;
+    if (!h || bytes == 0) return GS_OK;
+    hipError_t e = hipMalloc(d, bytes);
+    if (e != hipSuccess) return fail(c, GS_ERR_ALLOC, "hipMalloc(stage)", e);
+    bufs.push_back(*d);
+    return GS_OK;
+  }
+  int back(void* h, const void* d, size_t bytes) {
+    if (!h || bytes == 0) return GS_OK;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, GS_ERR_DEVICE, "sync", e);
+    e = hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(c, GS_ERR_DEVICE, "hipMemcpy D2H", e);
+    return GS_OK;
+  }
+};
+
+static int check_ctx(gs_ctx* c, bool need_crs) {
+  if (!c) return GS_ERR_ARG;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(c, GS_ERR_DEVICE, "hipSetDevice", e);
+  if (need_crs && !c->have_crs) return fail(c, GS_ERR_NOCRS, "gs_set_crs has not been called");
+  return GS_OK;
+}
+
+// Matrix<Com>::left_mul for a (k x 1) column: out[i] = sum_j lhs[i][j] col[j].
+// Expressed through the engine as `rows` proof-like elements with var tasks on both components.
+template <class C, class F>
+static int left_mul_impl(gs_ctx* c, int rows, int k, const void* lhs, const void* col, void* out) {
+  typedef Fr<C> S;
+  size_t com = 2 * sizeof(Aff<F>);
+  HostStage st(c);
+  void *dl, *dc, *dout;
+  RC(st.in(lhs, (size_t)rows * k * sizeof(S), &dl));
+  RC(st.in(col, (size_t)k * com, &dc));
+  RC(st.out(out, (size_t)rows * com, &dout));
+  // pool = canonical lhs via k_prep_verify (m*n scalars)
+  PoolMap pm;
+  memset(&pm, 0, sizeof pm);
+  pm.GC = 0;
+  pm.total = rows * k;
+  void* pool;
+  RC(scratch(c, "lm.pool", (size_t)pm.total * sizeof(S), &pool));
+  RC(launch(c, "k_prep_verify", k_prep_verify<C>, 1, 64, (size_t)1, rows, k, (const S*)dl, (const S*)nullptr,
+            (const S*)nullptr, (const S*)nullptr, pm, (S*)pool));
+  SidePlan sp;
+  int slot = 0;
+  for (int i = 0; i < rows; i++) {
+    int b[2], e[2];
+    for (int a = 0; a < 2; a++) {
+      b[a] = slot;
+      for (int j = 0; j < k; j++) sp.var.push_back(mkvar(i * k + j, 0, 2 * j + a, slot++));
+      e[a] = slot;
+    }
+    sp.red.push_back(mkred(b[0], e[0], b[1], e[1], 0, i));
+  }
+  sp.nslots = slot;
+  ArrTab arrs;
+  memset(&arrs, 0, sizeof arrs);
+  arrs.base[0] = (const uint8_t*)dc;
+  OutTab outs;
+  memset(&outs, 0, sizeof outs);
+  outs.base[0] = (uint8_t*)dout;
+  RC((run_side<C, F>(c, ".lm", 1, sp, arrs, (const S*)pool, pm.total, (const Aff<F>*)nullptr, outs)));
+  return st.back(out, dout, (size_t)rows * com);
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* gs_version(void) { return GS_VERSION; }
+
+int gs_sizes(int curve, size_t out[6]) {
+  if (curve != 0 && curve != 1) return GS_ERR_ARG;
+  size_t fq = sz_fq(curve);
+  out[0] = fq;
+  out[1] = SZ_FR;
+  out[2] = 2 * fq;
+  out[3] = 4 * fq;
+  out[4] = 12 * fq;
+  out[5] = 2 * 4 * fq + 2 * 8 * fq + 2 * fq + 4 * fq + 12 * fq;
+  return GS_OK;
+}
+
+int gs_ctx_create(int curve, int device, gs_ctx** out) {
+  if (!out || (curve != 0 && curve != 1)) return GS_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return GS_ERR_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return GS_ERR_DEVICE;
+  gs_ctx* c = new gs_ctx();
+  c->curve = curve;
+  c->device = device;
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return GS_ERR_DEVICE;
+  }
+  *out = c;
+  return GS_OK;
+}
+
+void gs_ctx_destroy(gs_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto& kv : c->scratch)
+    if (kv.second.p) hipFree(kv.second.p);
+  for (DevBuf* b : {&c->crs_g1, &c->crs_g2, &c->tab_g1, &c->tab_g2})
+    if (b->p) hipFree(b->p);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  delete c;
+}
+
+int gs_set_stream(gs_ctx* c, void* s) {
+  if (!c) return GS_ERR_ARG;
+  c->stream = (hipStream_t)s;
+  return GS_OK;
+}
+int gs_sync(gs_ctx* c) {
+  RC(check_ctx(c, false));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GS_OK;
+}
+const char* gs_last_error(gs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gs_set_crs(gs_ctx* c, const void* crs) {
+  RC(check_ctx(c, false));
+  if (!crs) return GS_ERR_ARG;
+  return DISPATCH(c, set_crs(c, crs));
+}
+
+// ---- commit ------------------------------------------------------------------
+#define COMMIT_DEV(NAME, FT, GROUP, TAB, TAG)                                                              \
+  int NAME(gs_ctx* c, size_t n, const void* v, const void* r, void* out) {                                 \
+    RC(check_ctx(c, true));                                                                                \
+    if (n == 0) return GS_OK;                                                                              \
+    if (!v || !r || !out) return GS_ERR_ARG;                                                               \
+    if (c->curve == 0)                                                                                     \
+      return Impl<Bls12_381>::commit<FT<Bls12_381>>(c, n, GROUP, v, r, out, (const Aff<FT<Bls12_381>>*)c->TAB.p, TAG); \
+    return Impl<Bn254>::commit<FT<Bn254>>(c, n, GROUP, v, r, out, (const Aff<FT<Bn254>>*)c->TAB.p, TAG);   \
+  }
+COMMIT_DEV(gs_commit_g1_dev, Fq, true, tab_g1, ".cg1")
+COMMIT_DEV(gs_commit_g2_dev, Fp2, true, tab_g2, ".cg2")
+COMMIT_DEV(gs_commit_fr_b1_dev, Fq, false, tab_g1, ".cg1")
+COMMIT_DEV(gs_commit_fr_b2_dev, Fp2, false, tab_g2, ".cg2")
+
+#define COMMIT_HOST(NAME, DEVNAME, VSZ, KC, OSZ)                           \
+  int NAME(gs_ctx* c, size_t n, const void* v, const void* r, void* out) { \
+    RC(check_ctx(c, true));                                                \
+    if (n == 0) return GS_OK;                                              \
+    if (!v || !r || !out) return GS_ERR_ARG;                               \
+    size_t fq = sz_fq(c->curve);                                           \
+    HostStage st(c);                                                       \
+    void *dv, *dr, *dout;                                                  \
+    RC(st.in(v, n * (VSZ), &dv));                                          \
+    RC(st.in(r, n * (KC)*SZ_FR, &dr));                                     \
+    RC(st.out(out, n * (OSZ), &dout));                                     \
+    RC(DEVNAME(c, n, dv, dr, dout));                                       \
+    return st.back(out, dout, n * (OSZ));                                  \
+  }
+COMMIT_HOST(gs_commit_g1, gs_commit_g1_dev, 2 * fq, 2, 4 * fq)
+COMMIT_HOST(gs_commit_g2, gs_commit_g2_dev, 4 * fq, 2, 8 * fq)
+COMMIT_HOST(gs_commit_fr_b1, gs_commit_fr_b1_dev, SZ_FR, 1, 4 * fq)
+COMMIT_HOST(gs_commit_fr_b2, gs_commit_fr_b2_dev, SZ_FR, 1, 8 * fq)
+
+// ---- prove -------------------------------------------------------------------
+static int check_shape(gs_ctx* c, int ty, int m, int n) {
+  if (ty < 0 || ty > 3) return fail(c, GS_ERR_ARG, "bad equation type");
+  // the reference indexes rand[0] / gamma[0]: empty variable lists panic (prove.rs:106-113)
+  if (m < 1 || n < 1) return fail(c, GS_ERR_SHAPE, "m and n must be >= 1 (reference asserts, prove.rs:106-113)");
+  if (m > 4096 || n > 4096 || (long)m * n > 60000) return fail(c, GS_ERR_SHAPE, "shape too large for task tables");
+  return GS_OK;
+}
+
+int gs_prove_batch_dev(gs_ctx* c, int ty, size_t N, int m, int n, const void* X, const void* Y, const void* A,
+                       const void* B, const void* G, const void* R, const void* S, const void* T, void* xcoms,
+                       void* ycoms, void* pi, void* theta) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (N == 0) return GS_OK;
+  if (!X || !Y || !A || !B || !G || !R || !S || !T || !pi || !theta) return fail(c, GS_ERR_ARG, "null pointer");
+  return DISPATCH(c, prove(c, ty, N, m, n, X, Y, A, B, G, R, S, T, xcoms, ycoms, pi, theta));
+}
+
+int gs_prove_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* X, const void* Y, const void* A,
+                   const void* B, const void* G, const void* R, const void* S, const void* T, void* xcoms,
+                   void* ycoms, void* pi, void* theta) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (N == 0) return GS_OK;
+  size_t fq = sz_fq(c->curve);
+  bool xg = x_is_group(ty), yg = y_is_group(ty);
+  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
+  HostStage st(c);
+  void *dX, *dY, *dA, *dB, *dG, *dR, *dS, *dT, *dxc, *dyc, *dpi, *dth;
+  RC(st.in(X, N * m * sx, &dX));
+  RC(st.in(Y, N * n * sy, &dY));
+  RC(st.in(A, N * n * sx, &dA));
+  RC(st.in(B, N * m * sy, &dB));
+  RC(st.in(G, N * m * n * SZ_FR, &dG));
+  RC(st.in(R, N * m * kx * SZ_FR, &dR));
+  RC(st.in(S, N * n * ky * SZ_FR, &dS));
+  RC(st.in(T, N * ky * kx * SZ_FR, &dT));
+  RC(st.out(xcoms, N * m * 4 * fq, &dxc));
+  RC(st.out(ycoms, N * n * 8 * fq, &dyc));
+  RC(st.out(pi, N * kx * 8 * fq, &dpi));
+  RC(st.out(theta, N * ky * 4 * fq, &dth));
+  RC(gs_prove_batch_dev(c, ty, N, m, n, dX, dY, dA, dB, dG, dR, dS, dT, dxc, dyc, dpi, dth));
+  RC(st.back(xcoms, dxc, N * m * 4 * fq));
+  RC(st.back(ycoms, dyc, N * n * 8 * fq));
+  RC(st.back(pi, dpi, N * kx * 8 * fq));
+  return st.back(theta, dth, N * ky * 4 * fq);
+}
+
+// ---- verify ------------------------------------------------------------------
+int gs_verify_batch_dev(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                        const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                        uint8_t* ok) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (N == 0) return GS_OK;
+  if (!A || !B || !G || !target || !xcoms || !ycoms || !pi || !theta || !ok) return fail(c, GS_ERR_ARG, "null pointer");
+  return DISPATCH(c, verify(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, ok));
+}
+
+int gs_verify_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                    const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                    uint8_t* ok) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (N == 0) return GS_OK;
+  size_t fq = sz_fq(c->curve);
+  bool xg = x_is_group(ty), yg = y_is_group(ty);
+  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
+  size_t st_ = ty == GS_PPE ? 12 * fq : ty == GS_MSMEG1 ? 2 * fq : ty == GS_MSMEG2 ? 4 * fq : SZ_FR;
+  HostStage st(c);
+  void *dA, *dB, *dG, *dt, *dxc, *dyc, *dpi, *dth, *dok;
+  RC(st.in(A, N * n * sx, &dA));
+  RC(st.in(B, N * m * sy, &dB));
+  RC(st.in(G, N * m * n * SZ_FR, &dG));
+  RC(st.in(target, N * st_, &dt));
+  RC(st.in(xcoms, N * m * 4 * fq, &dxc));
+  RC(st.in(ycoms, N * n * 8 * fq, &dyc));
+  RC(st.in(pi, N * kx * 8 * fq, &dpi));
+  RC(st.in(theta, N * ky * 4 * fq, &dth));
+  RC(st.out(ok, N, &dok));
+  RC(gs_verify_batch_dev(c, ty, N, m, n, dA, dB, dG, dt, dxc, dyc, dpi, dth, (uint8_t*)dok));
+  return st.back(ok, dok, N);
+}
+
+// ---- helpers / hooks -----------------------------------------------------------
+int gs_g1_mul_batch_dev(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
+  RC(check_ctx(c, false));
+  if (n == 0) return GS_OK;
+  if (c->curve == 0)
+    return launch(c, "k_smul_batch.g1", k_smul_batch<Bls12_381, Fq<Bls12_381>>, n, 64, n,
+                  (const Aff<Fq<Bls12_381>>*)p, bc, (const Fr<Bls12_381>*)k, (Aff<Fq<Bls12_381>>*)out);
+  return launch(c, "k_smul_batch.g1", k_smul_batch<Bn254, Fq<Bn254>>, n, 64, n, (const Aff<Fq<Bn254>>*)p, bc,
+                (const Fr<Bn254>*)k, (Aff<Fq<Bn254>>*)out);
+}
+int gs_g2_mul_batch_dev(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
+  RC(check_ctx(c, false));
+  if (n == 0) return GS_OK;
+  if (c->curve == 0)
+    return launch(c, "k_smul_batch.g2", k_smul_batch<Bls12_381, Fp2<Bls12_381>>, n, 64, n,
+                  (const Aff<Fp2<Bls12_381>>*)p, bc, (const Fr<Bls12_381>*)k, (Aff<Fp2<Bls12_381>>*)out);
+  return launch(c, "k_smul_batch.g2", k_smul_batch<Bn254, Fp2<Bn254>>, n, 64, n, (const Aff<Fp2<Bn254>>*)p, bc,
+                (const Fr<Bn254>*)k, (Aff<Fp2<Bn254>>*)out);
+}
+int gs_g1_mul_batch(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
+  RC(check_ctx(c, false));
+  size_t fq = sz_fq(c->curve);
+  HostStage st(c);
+  void *dp, *dk, *dout;
+  RC(st.in(p, (bc ? 1 : n) * 2 * fq, &dp));
+  RC(st.in(k, n * SZ_FR, &dk));
+  RC(st.out(out, n * 2 * fq, &dout));
+  RC(gs_g1_mul_batch_dev(c, n, dp, bc, dk, dout));
+  return st.back(out, dout, n * 2 * fq);
+}
+int gs_g2_mul_batch(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
+  RC(check_ctx(c, false));
+  size_t fq = sz_fq(c->curve);
+  HostStage st(c);
+  void *dp, *dk, *dout;
+  RC(st.in(p, (bc ? 1 : n) * 4 * fq, &dp));
+  RC(st.in(k, n * SZ_FR, &dk));
+  RC(st.out(out, n * 4 * fq, &dout));
+  RC(gs_g2_mul_batch_dev(c, n, dp, bc, dk, dout));
+  return st.back(out, dout, n * 4 * fq);
+}
+
+int gs_multi_pairing_batch_dev(gs_ctx* c, size_t n, int k, const void* p, const void* q, void* out) {
+  RC(check_ctx(c, false));
+  if (n == 0) return GS_OK;
+  if (k < 0) return GS_ERR_ARG;
+  if (c->curve == 0)
+    return launch(c, "k_multi_pairing", k_multi_pairing<Bls12_381>, n, 64, n, k, (const Aff<Fq<Bls12_381>>*)p,
+                  (const Aff<Fp2<Bls12_381>>*)q, (Fp12<Bls12_381>*)out);
+  return launch(c, "k_multi_pairing", k_multi_pairing<Bn254>, n, 64, n, k, (const Aff<Fq<Bn254>>*)p,
+                (const Aff<Fp2<Bn254>>*)q, (Fp12<Bn254>*)out);
+}
+int gs_multi_pairing_batch(gs_ctx* c, size_t n, int k, const void* p, const void* q, void* out) {
+  RC(check_ctx(c, false));
+  size_t fq = sz_fq(c->curve);
+  HostStage st(c);
+  void *dp, *dq, *dout;
+  RC(st.in(p, n * k * 2 * fq, &dp));
+  RC(st.in(q, n * k * 4 * fq, &dq));
+  RC(st.out(out, n * 12 * fq, &dout));
+  RC(gs_multi_pairing_batch_dev(c, n, k, dp, dq, dout));
+  return st.back(out, dout, n * 12 * fq);
+}
+
+int gs_gt_pow_batch_dev(gs_ctx* c, size_t n, const void* base, const void* k, void* out) {
+  RC(check_ctx(c, false));
+  if (n == 0) return GS_OK;
+  if (c->curve == 0)
+    return launch(c, "k_gt_pow", k_gt_pow<Bls12_381>, n, 64, n, (const Fp12<Bls12_381>*)base,
+                  (const Fr<Bls12_381>*)k, (Fp12<Bls12_381>*)out);
+  return launch(c, "k_gt_pow", k_gt_pow<Bn254>, n, 64, n, (const Fp12<Bn254>*)base, (const Fr<Bn254>*)k,
+                (Fp12<Bn254>*)out);
+}
+
+// ComT::pairing_sum: four multi-pairings over the component selections (a,b)
+int gs_pairing_sum(gs_ctx* c, int k, const void* x, const void* y, void* out) {
+  RC(check_ctx(c, false));
+  if (k < 0) return GS_ERR_ARG;
+  size_t fq = sz_fq(c->curve);
+  size_t g1 = 2 * fq, g2 = 4 * fq;
+  std::vector<uint8_t> P(4 * (size_t)k * g1 + 1), Q(4 * (size_t)k * g2 + 1);
+  const uint8_t* xb = (const uint8_t*)x;
+  const uint8_t* yb = (const uint8_t*)y;
+  for (int cell = 0; cell < 4; cell++) {
+    int a = cell >> 1, b = cell & 1;
+    for (int i = 0; i < k; i++) {
+      memcpy(&P[((size_t)cell * k + i) * g1], xb + (size_t)i * 2 * g1 + a * g1, g1);
+      memcpy(&Q[((size_t)cell * k + i) * g2], yb + (size_t)i * 2 * g2 + b * g2, g2);
+    }
+  }
+  if (k == 0) {  // empty sum: four GT identities
+    gs_ctx* cc = c;
+    (void)cc;
+  }
+  return gs_multi_pairing_batch(c, 4, k, P.data(), Q.data(), out);
+}
+
+int gs_mat_left_mul_com1(gs_ctx* c, int rows, int k, const void* lhs, const void* col, void* out) {
+  RC(check_ctx(c, false));
+  if (rows <= 0 || k <= 0) return GS_OK;  // empty product (data_structures.rs:697-702)
+  if (c->curve == 0) return left_mul_impl<Bls12_381, Fq<Bls12_381>>(c, rows, k, lhs, col, out);
+  return left_mul_impl<Bn254, Fq<Bn254>>(c, rows, k, lhs, col, out);
+}
+int gs_mat_left_mul_com2(gs_ctx* c, int rows, int k, const void* lhs, const void* col, void* out) {
+  RC(check_ctx(c, false));
+  if (rows <= 0 || k <= 0) return GS_OK;
+  if (c->curve == 0) return left_mul_impl<Bls12_381, Fp2<Bls12_381>>(c, rows, k, lhs, col, out);
+  return left_mul_impl<Bn254, Fp2<Bn254>>(c, rows, k, lhs, col, out);
+}
+
+// ---- RLC mode: implemented in a later milestone ---------------------------------
+int gs_verify_batch_rlc_dev(gs_ctx* c, int, size_t, int, int, const void*, const void*, const void*, const void*,
+                            const void*, const void*, const void*, const void*, const uint64_t*, void*) {
+  return fail(c, GS_ERR_ARG, "gs_verify_batch_rlc: not implemented yet");
+}
+int gs_verify_batch_rlc(gs_ctx* c, int, size_t, int, int, const void*, const void*, const void*, const void*,
+                        const void*, const void*, const void*, const void*, const uint64_t*, void*, uint8_t*) {
+  return fail(c, GS_ERR_ARG, "gs_verify_batch_rlc: not implemented yet");
+}
+int gs_gt_finalize(gs_ctx* c, size_t, const void*, uint8_t*) {
+  return fail(c, GS_ERR_ARG, "gs_gt_finalize: not implemented yet");
+}
+
+// ---- profiling ---------------------------------------------------------------------
+int gs_prof_enable(gs_ctx* c, int on) {
+  if (!c) return GS_ERR_ARG;
+  c->prof = on != 0;
+  return GS_OK;
+}
+int gs_prof_reset(gs_ctx* c) {
+  if (!c) return GS_ERR_ARG;
+  c->prof_map.clear();
+  c->prof_order.clear();
+  return GS_OK;
+}
+int gs_prof_get(gs_ctx* c, int idx, char* name, size_t cap, double* ms, uint64_t* n) {
+  if (!c || idx < 0 || (size_t)idx >= c->prof_order.size()) return GS_ERR_ARG;
+  const std::string& k = c->prof_order[idx];
+  if (name && cap) {
+    strncpy(name, k.c_str(), cap - 1);
+    name[cap - 1] = 0;
+  }
+  if (ms) *ms = c->prof_map[k].ms;
+  if (n) *n = c->prof_map[k].n;
+  return GS_OK;
+}
+
+}  // extern "C"

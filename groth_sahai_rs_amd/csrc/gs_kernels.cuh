@@ -1,0 +1,346 @@
+// Device kernels of the Groth-Sahai engine.  One lane = one task; a task is a
+// descriptor-driven unit of group arithmetic, so that the four equation types
+// of the reference (src/statement.rs:117-192) and both groups share the same
+// handful of kernels.  Per batch the host (gs_amd.hip) uploads small per-shape
+// task tables; per-equation data is addressed as  base[arr] + eq*stride[arr].
+//
+//   k_prep_*   Fr mini-GEMMs  Psi = R^T Gamma, Omega = Psi S - T^T, Phi = S^T Gamma^T
+//              (prove.rs:133,139-142,154) -> canonical scalars in the "pool"
+//   k_var      one variable-base scalar multiplication per lane (Jacobian out)
+//   k_fix      <= 2 fixed-base terms from the CRS window tables (+ affine addend)
+//   k_red      sum the partial slots of a commitment-group element, ONE shared
+//              inversion per element (Montgomery trick), normalised affine out
+//   k_miller   multi-Miller loop over <= 3 pairs  -> un-exponentiated Fp12
+//   k_final    product of a cell's partial Miller values, final exponentiation,
+//              compare (verifier.rs:50-53)
+#pragma once
+#include "gs_pairing.cuh"
+
+namespace gs {
+
+constexpr int MAX_ARR = 8;
+struct ArrTab {
+  const uint8_t* base[MAX_ARR];
+  uint32_t stride[MAX_ARR];  // bytes per equation; 0 = shared by the whole batch
+};
+struct OutTab {
+  uint8_t* base[4];
+  uint32_t stride[4];
+};
+struct VarTask {
+  uint16_t s_idx, p_idx, slot;
+  uint8_t p_arr, pad;
+};
+struct FixTask {
+  uint16_t s0, s1, a_idx, slot;
+  uint8_t t0, t1, a_arr, a_neg;  // 0xFF = absent
+};
+struct RedTask {
+  uint16_t b0, e0, b1, e1, out_idx;
+  uint8_t out_arr, pad;
+};
+struct PairRef {
+  uint8_t p_arr, q_arr, neg, pad;
+  uint16_t p_idx, q_idx;
+};
+constexpr int MILLER_CH = 3;
+struct MillerTask {
+  uint8_t np, cell, pad0, pad1;
+  PairRef pr[MILLER_CH];
+};
+struct PoolMap {  // offsets (in scalars) into the per-equation pool
+  int RC, SC, PSI, PHI, OM, TC, RHO, SIG, XC, YC, GC, AC, BC, NT, total;
+};
+
+template <class T> __device__ __forceinline__ T ld(const uint8_t* p) { return *reinterpret_cast<const T*>(p); }
+
+// --------------------------------------------------------------------------
+// generic helpers
+// --------------------------------------------------------------------------
+template <class C, class F>
+__global__ void __launch_bounds__(64) k_smul_batch(size_t n, const Aff<F>* p, int broadcast, const Fr<C>* k,
+                                                   Aff<F>* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> P = p[broadcast ? 0 : i];
+  Jac<F> J;
+  jac_smul(J, P, from_mont(k[i]));
+  Aff<F> R;
+  jac_to_aff(R, J);
+  out[i] = R;
+}
+
+// pts[5] <- pts[3] + pts[5]  (W.1 = u1.1 + generator), single lane
+template <class C, class F> __global__ void k_crs_derive(Aff<F>* pts) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Jac<F> j;
+  jac_from_aff(j, pts[3]);
+  jac_madd(j, j, pts[5]);
+  Aff<F> r;
+  jac_to_aff(r, j);
+  pts[5] = r;
+}
+
+// window tables: tab[(b*32 + w)*256 + d] = d * 2^(8w) * base[b]   (d = 0 -> identity)
+template <class C, class F>
+__global__ void __launch_bounds__(64) k_build_tables(int nb, const Aff<F>* bases, Aff<F>* tab) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nb * 32 * 256) return;
+  int d = (int)(i & 255), w = (int)((i >> 8) & 31), b = (int)(i >> 13);
+  Fr<C> k = fzero<FrM<C>>();
+  k.v[w >> 2] = (uint32_t)d << ((w & 3) * 8);
+  Jac<F> J;
+  jac_smul(J, bases[b], k);
+  Aff<F> R;
+  jac_to_aff(R, J);
+  tab[i] = R;
+}
+
+// --------------------------------------------------------------------------
+// Fr preparation for prove (one lane per equation)
+// --------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64)
+    k_prep_prove(size_t N, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R, const Fr<C>* S,
+                 const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm,
+                 Fr<C>* pool) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  typedef Fr<C> S_;
+  G += e * m * n;
+  R += e * m * kx;
+  S += e * n * ky;
+  T += e * ky * kx;
+  S_* P = pool + e * pm.total;
+  for (int i = 0; i < m * kx; i++) P[pm.RC + i] = from_mont(R[i]);
+  for (int i = 0; i < n * ky; i++) P[pm.SC + i] = from_mont(S[i]);
+  for (int i = 0; i < ky * kx; i++) P[pm.TC + i] = from_mont(T[i]);
+  if (xs)
+    for (int i = 0; i < m; i++) P[pm.XC + i] = from_mont(xs[e * m + i]);
+  if (ys)
+    for (int j = 0; j < n; j++) P[pm.YC + j] = from_mont(ys[e * n + j]);
+  // Psi = R^T Gamma (kx x n); Omega = Psi S - T^T (kx x ky); rho_k (scalar-Y types)
+  for (int k = 0; k < kx; k++) {
+    S_ om[2] = {fzero<FrM<C>>(), fzero<FrM<C>>()};
+    S_ rho = fzero<FrM<C>>();
+    for (int j = 0; j < n; j++) {
+      S_ psi = fzero<FrM<C>>();
+      for (int i = 0; i < m; i++) psi = add(psi, mul(R[i * kx + k], G[i * n + j]));
+      P[pm.PSI + k * n + j] = from_mont(psi);
+      for (int l = 0; l < ky; l++) om[l] = add(om[l], mul(psi, S[j * ky + l]));
+      if (ys) rho = add(rho, mul(psi, ys[e * n + j]));
+    }
+    for (int l = 0; l < ky; l++) P[pm.OM + k * ky + l] = from_mont(sub(om[l], T[l * kx + k]));
+    if (bs) {
+      for (int i = 0; i < m; i++) rho = add(rho, mul(R[i * kx + k], bs[e * m + i]));
+      P[pm.RHO + k] = from_mont(rho);
+    }
+  }
+  // Phi = S^T Gamma^T (ky x m); sigma_l (scalar-X types)
+  for (int l = 0; l < ky; l++) {
+    S_ sig = fzero<FrM<C>>();
+    for (int i = 0; i < m; i++) {
+      S_ phi = fzero<FrM<C>>();
+      for (int j = 0; j < n; j++) phi = add(phi, mul(S[j * ky + l], G[i * n + j]));
+      P[pm.PHI + l * m + i] = from_mont(phi);
+      if (xs) sig = add(sig, mul(phi, xs[e * m + i]));
+    }
+    if (as) {
+      for (int j = 0; j < n; j++) sig = add(sig, mul(S[j * ky + l], as[e * n + j]));
+      P[pm.SIG + l] = from_mont(sig);
+    }
+  }
+}
+
+// Fr preparation for verify: Gamma (and scalar constants / target) -> canonical
+template <class C>
+__global__ void __launch_bounds__(64) k_prep_verify(size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as,
+                                                    const Fr<C>* bs, const Fr<C>* tq, PoolMap pm, Fr<C>* pool) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  Fr<C>* P = pool + e * pm.total;
+  for (int i = 0; i < m * n; i++) P[pm.GC + i] = from_mont(G[e * m * n + i]);
+  if (as)
+    for (int j = 0; j < n; j++) P[pm.AC + j] = from_mont(as[e * n + j]);
+  if (bs)
+    for (int i = 0; i < m; i++) P[pm.BC + i] = from_mont(bs[e * m + i]);
+  if (tq) P[pm.NT] = from_mont(neg(tq[e]));
+}
+
+// --------------------------------------------------------------------------
+// linear-combination engine
+// --------------------------------------------------------------------------
+template <class C, class F>
+__global__ void __launch_bounds__(64) k_var(size_t total, int ntask, const VarTask* tasks, ArrTab arrs,
+                                            const Fr<C>* pool, int pool_n, Jac<F>* part, int nslots) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / ntask;
+  VarTask t = tasks[g % ntask];
+  Fr<C> k = pool[e * pool_n + t.s_idx];
+  Aff<F> P = ld<Aff<F>>(arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * sizeof(Aff<F>));
+  Jac<F> J;
+  jac_smul(J, P, k);
+  part[e * nslots + t.slot] = J;
+}
+
+template <class C, class F>
+__global__ void __launch_bounds__(64) k_fix(size_t total, int ntask, const FixTask* tasks, ArrTab arrs,
+                                            const Fr<C>* pool, int pool_n, const Aff<F>* tab, Jac<F>* part,
+                                            int nslots) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / ntask;
+  FixTask t = tasks[g % ntask];
+  Jac<F> acc;
+  jac_set_inf(acc);
+  for (int term = 0; term < 2; term++) {
+    int tb = term ? t.t1 : t.t0;
+    if (tb == 0xFF) continue;
+    Fr<C> k = pool[e * pool_n + (term ? t.s1 : t.s0)];
+    const Aff<F>* T = tab + (size_t)tb * 32 * 256;
+    for (int w = 0; w < 32; w++) {
+      uint32_t d = (k.v[w >> 2] >> ((w & 3) * 8)) & 255u;
+      if (d) {
+        Aff<F> q = T[w * 256 + d];
+        jac_madd(acc, acc, q);
+      }
+    }
+  }
+  if (t.a_arr != 0xFF) {
+    Aff<F> q = ld<Aff<F>>(arrs.base[t.a_arr] + e * arrs.stride[t.a_arr] + (size_t)t.a_idx * sizeof(Aff<F>));
+    if (t.a_neg) q.y = neg(q.y);
+    jac_madd(acc, acc, q);
+  }
+  part[e * nslots + t.slot] = acc;
+}
+
+template <class C, class F>
+__global__ void __launch_bounds__(64) k_red(size_t total, int ntask, const RedTask* tasks, const Jac<F>* part,
+                                            int nslots, OutTab outs) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / ntask;
+  RedTask t = tasks[g % ntask];
+  const Jac<F>* P = part + e * nslots;
+  Jac<F> s0 = P[t.b0], s1 = P[t.b1];
+  for (int i = t.b0 + 1; i < t.e0; i++) jac_add(s0, s0, P[i]);
+  for (int i = t.b1 + 1; i < t.e1; i++) jac_add(s1, s1, P[i]);
+  // one inversion for both components
+  bool i0 = is_zero(s0.z), i1 = is_zero(s1.z);
+  F z0 = i0 ? one_of<F>() : s0.z, z1 = i1 ? one_of<F>() : s1.z;
+  F zi = inv(mul(z0, z1));
+  F zi0 = mul(zi, z1), zi1 = mul(zi, z0);
+  Aff<F> a0, a1;
+  jac_to_aff_zinv(a0, s0, zi0);
+  jac_to_aff_zinv(a1, s1, zi1);
+  Aff<F>* o = reinterpret_cast<Aff<F>*>(outs.base[t.out_arr] + e * outs.stride[t.out_arr]) + 2 * (size_t)t.out_idx;
+  o[0] = a0;
+  o[1] = a1;
+}
+
+// --------------------------------------------------------------------------
+// pairing side
+// --------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) k_miller(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
+                                               ArrTab qarr, Fp12<C>* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / ntask;
+  MillerTask t = tasks[g % ntask];
+  Aff<Fq<C>> ps[MILLER_CH];
+  Aff<Fp2<C>> qs[MILLER_CH];
+  Proj2<C> ts[MILLER_CH];
+  bool live[MILLER_CH];
+  for (int k = 0; k < t.np; k++) {
+    PairRef r = t.pr[k];
+    ps[k] = ld<Aff<Fq<C>>>(parr.base[r.p_arr] + e * parr.stride[r.p_arr] + (size_t)r.p_idx * sizeof(Aff<Fq<C>>));
+    qs[k] = ld<Aff<Fp2<C>>>(qarr.base[r.q_arr] + e * qarr.stride[r.q_arr] + (size_t)r.q_idx * sizeof(Aff<Fp2<C>>));
+    if (r.neg) ps[k].y = neg(ps[k].y);
+  }
+  Fp12<C> f;
+  multi_miller(f, ps, qs, t.np, ts, live);
+  out[g] = f;
+}
+
+// cell_begin[c]..cell_begin[c+1] = the Miller tasks of cell c.  mode 0: exact
+// check (FE, compare with 1 or the PPE target) -> cellok[e*4+c].
+template <class C>
+__global__ void __launch_bounds__(64) k_final(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4,
+                                              const Fp12<C>* mpart, const Fp12<C>* target, uint8_t* cellok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * 4) return;
+  size_t e = g >> 2;
+  int c = (int)(g & 3);
+  int b = c == 0 ? cb0 : c == 1 ? cb1 : c == 2 ? cb2 : cb3;
+  int en = c == 0 ? cb1 : c == 1 ? cb2 : c == 2 ? cb3 : cb4;
+  Fp12<C> f = mpart[e * ntask + b];
+  for (int i = b + 1; i < en; i++) f12_mul(f, f, mpart[e * ntask + i]);
+  Fp12<C> r;
+  final_exp(r, f);
+  bool ok;
+  if (c == 3 && target) {
+    Fp12<C> t = target[e];
+    ok = f12_eq(r, t);
+  } else {
+    ok = f12_is_one(r);
+  }
+  cellok[g] = ok ? 1 : 0;
+}
+
+__global__ void k_and4(size_t N, const uint8_t* cellok, uint8_t* ok) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const uint8_t* c = cellok + e * 4;
+  ok[e] = (c[0] & c[1] & c[2] & c[3]) ? 1 : 0;
+}
+
+// E::multi_pairing per row: k pairs -> Miller product -> final exponentiation
+template <class C>
+__global__ void __launch_bounds__(64) k_multi_pairing(size_t n, int k, const Aff<Fq<C>>* P, const Aff<Fp2<C>>* Q,
+                                                      Fp12<C>* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Aff<Fq<C>> ps[MILLER_CH];
+  Aff<Fp2<C>> qs[MILLER_CH];
+  Proj2<C> ts[MILLER_CH];
+  bool live[MILLER_CH];
+  Fp12<C> acc, f;
+  f12_one(acc);
+  for (int b = 0; b < k; b += MILLER_CH) {
+    int np = k - b < MILLER_CH ? k - b : MILLER_CH;
+    for (int i = 0; i < np; i++) {
+      ps[i] = P[g * k + b + i];
+      qs[i] = Q[g * k + b + i];
+    }
+    multi_miller(f, ps, qs, np, ts, live);
+    f12_mul(acc, acc, f);
+  }
+  final_exp(f, acc);
+  out[g] = f;
+}
+
+// out[i] = base^(k[i]) for base in GT (cyclotomic squarings are valid)
+template <class C>
+__global__ void __launch_bounds__(64) k_gt_pow(size_t n, const Fp12<C>* base, const Fr<C>* k, Fp12<C>* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Fr<C> s = from_mont(k[g]);
+  Fp12<C> b = base[0], acc;
+  f12_one(acc);
+  bool started = false;
+  for (int i = FrM<C>::BITS - 1; i >= 0; i--) {
+    if (started) f12_cyclo_sqr(acc, acc);
+    if (get_bit(s, i)) {
+      if (started)
+        f12_mul(acc, acc, b);
+      else
+        acc = b;
+      started = true;
+    }
+  }
+  out[g] = acc;
+}
+
+}  // namespace gs

@@ -1,0 +1,149 @@
+/* gs_amd.h -- C ABI of the MI355X-native Groth-Sahai prove/verify engine.
+ *
+ * Drop-in boundary for the hot path of jdwhite48/groth-sahai-rs.  The reference
+ * has no FFI layer; these entry points are what a Rust `extern "C"` shim
+ * implementing its public traits would bind (INTEGRATION.md shows the shim):
+ *
+ *   gs_commit_*            <- src/prover/commit.rs:59-256  (commit_G1, batch_commit_G1, ... scalar_to_B2)
+ *   gs_prove_batch         <- src/prover/prove.rs:92-171,195-274,298-379,409-488  (Provable::prove)
+ *   gs_commit_and_prove_batch <- src/prover/prove.rs:72-90,175-193,278-296,383-408
+ *   gs_verify_batch        <- src/verifier.rs:23-157       (Verifiable::verify, exact semantics, bool per equation)
+ *   gs_verify_batch_rlc    <- (new) batched pairing-product check, one final exponentiation per batch
+ *   gs_mat_left_mul_com1/2 <- src/data_structures.rs:696-742 (Mat::left_mul on Matrix<Com1/Com2>)
+ *   gs_pairing_sum         <- src/data_structures.rs:494-502 (ComT::pairing_sum)
+ *   gs_set_crs             <- consumes src/generator.rs:35-42 (struct CRS)
+ *
+ * DATA LAYOUT (arkworks' in-memory limbs; all little-endian):
+ *   Fq  = NQ u64 limbs of a*2^(64 NQ) mod p   (BLS12-381: NQ=6, 48 B; BN254: NQ=4, 32 B)
+ *   Fr  = 4 u64 limbs of a*2^256 mod r        (32 B, Montgomery)
+ *   G1  = x || y                (identity = all-zero bytes)
+ *   G2  = x.c0 || x.c1 || y.c0 || y.c1        (identity = all-zero bytes)
+ *   Com1 = G1 || G1,  Com2 = G2 || G2
+ *   GT  = 12 Fq, order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1
+ *   CRS = u[0],u[1] (Com1) || v[0],v[1] (Com2) || g1 || g2 || gt
+ * Batches are arrays-of-structs, equation-major, row-major inside an equation
+ * (Gamma[N][m][n], R[N][m][kx], S[N][n][ky], T[N][ky][kx]).
+ *
+ * Equation types and shapes (kx = columns of R = #pi, ky = columns of S = #theta):
+ *   GS_PPE    : X in G1^m, Y in G2^n, A in G1^n, B in G2^m, target GT,  kx=2, ky=2
+ *   GS_MSMEG1 : X in G1^m, y in Fr^n, A in G1^n, b in Fr^m, target G1,  kx=2, ky=1
+ *   GS_MSMEG2 : x in Fr^m, Y in G2^n, a in Fr^n, B in G2^m, target G2,  kx=1, ky=2
+ *   GS_QUAD   : x in Fr^m, y in Fr^n, a in Fr^n, b in Fr^m, target Fr,  kx=1, ky=1
+ *
+ * Randomness (R, S, T) is ALWAYS an input: the shim draws it from the caller's
+ * Rng in the reference's order (R row-major, then S, then T).
+ *
+ * Pointers: the *_dev entry points take DEVICE pointers (hipMalloc'ed, 16-byte
+ * aligned) and enqueue on the context's stream without synchronising; the
+ * un-suffixed ones take HOST pointers, stage through device memory and return
+ * after the results are back.  A gs_ctx is bound to one GPU and may be used from
+ * one host thread at a time.  Points must lie in the prime-order subgroups (as
+ * arkworks' deserialisation guarantees); like the reference, nothing is checked.
+ *
+ * Errors: the reference panics on shape mismatch (assert_eq!, e.g.
+ * src/prover/prove.rs:106-113); here every call returns a status and a shim
+ * turns GS_ERR_SHAPE back into a panic.  There is NO CPU fallback: without a
+ * usable GPU every compute call returns GS_ERR_DEVICE.
+ */
+#ifndef GS_AMD_H
+#define GS_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gs_ctx gs_ctx;
+
+enum { GS_CURVE_BLS12_381 = 0, GS_CURVE_BN254 = 1 };
+enum { GS_PPE = 0, GS_MSMEG1 = 1, GS_MSMEG2 = 2, GS_QUAD = 3 }; /* = EquType, src/statement.rs:42-49 */
+enum { GS_OK = 0, GS_ERR_SHAPE = 1, GS_ERR_DEVICE = 2, GS_ERR_ARG = 3, GS_ERR_NOCRS = 4, GS_ERR_ALLOC = 5 };
+
+/* ---- context ---------------------------------------------------------- */
+int gs_ctx_create(int curve_id, int device_ordinal, gs_ctx** out);
+void gs_ctx_destroy(gs_ctx* ctx);
+int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default stream */
+int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the context's stream */
+const char* gs_last_error(gs_ctx* ctx);
+const char* gs_version(void);
+/* sizes in bytes of the boundary PODs for a curve: out[0..5] = Fq, Fr, G1, G2, GT, CRS */
+int gs_sizes(int curve_id, size_t out[6]);
+
+/* CRS (host pointer): uploads, derives W1 = u[1]+(O,g1), W2 = v[1]+(O,g2) and
+ * builds the windowed fixed-base tables on the device. */
+int gs_set_crs(gs_ctx* ctx, const void* crs_host);
+
+/* ---- commit (src/prover/commit.rs) -------------------------------------- */
+/* c_i = iota1(X_i) + r_i0 u0 + r_i1 u1   (commit.rs:78-100; N=1 is commit_G1 :59-75) */
+int gs_commit_g1_dev(gs_ctx*, size_t count, const void* x_g1, const void* rand_fr2, void* out_com1);
+int gs_commit_g2_dev(gs_ctx*, size_t count, const void* y_g2, const void* rand_fr2, void* out_com2);
+/* c_i = x_i W1 + r_i u0                  (commit.rs:125-156, 225-256) */
+int gs_commit_fr_b1_dev(gs_ctx*, size_t count, const void* x_fr, const void* rand_fr, void* out_com1);
+int gs_commit_fr_b2_dev(gs_ctx*, size_t count, const void* y_fr, const void* rand_fr, void* out_com2);
+int gs_commit_g1(gs_ctx*, size_t count, const void* x_g1, const void* rand_fr2, void* out_com1);
+int gs_commit_g2(gs_ctx*, size_t count, const void* y_g2, const void* rand_fr2, void* out_com2);
+int gs_commit_fr_b1(gs_ctx*, size_t count, const void* x_fr, const void* rand_fr, void* out_com1);
+int gs_commit_fr_b2(gs_ctx*, size_t count, const void* y_fr, const void* rand_fr, void* out_com2);
+
+/* ---- prove (src/prover/prove.rs) ---------------------------------------- */
+/* Batch of N independent equations of one type and shape over the shared CRS.
+ * xcoms/ycoms may be NULL (prove only) or receive the commitments
+ * (commit_and_prove).  pi: N*kx Com2, theta: N*ky Com1. */
+int gs_prove_batch_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const void* X, const void* Y, const void* A,
+                       const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
+                       void* ycoms, void* pi, void* theta);
+int gs_prove_batch(gs_ctx*, int equ_type, size_t N, int m, int n, const void* X, const void* Y, const void* A,
+                   const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
+                   void* ycoms, void* pi, void* theta);
+
+/* ---- verify (src/verifier.rs) ------------------------------------------- */
+/* ok[i] = 1 iff equation i verifies; exact reference semantics (four GT cell
+ * equalities per equation). */
+int gs_verify_batch_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A, const void* B,
+                        const void* Gamma, const void* target, const void* xcoms, const void* ycoms, const void* pi,
+                        const void* theta, uint8_t* ok);
+int gs_verify_batch(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A, const void* B, const void* Gamma,
+                    const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                    uint8_t* ok);
+/* Batched pairing-product check: random linear combination of all 4N cell
+ * equations with caller-supplied 64-bit exponents rho[N][4] (device/host u64),
+ * one final exponentiation for the whole batch.  *ok_all = 1 iff the combined
+ * check passes; acc (may be NULL) receives the un-exponentiated GT accumulator
+ * (one GT) so that ranks can multiply accumulators before exponentiating:
+ * gs_gt_finalize(prod of accs) gives the same verdict for the union. */
+int gs_verify_batch_rlc_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A, const void* B,
+                            const void* Gamma, const void* target, const void* xcoms, const void* ycoms,
+                            const void* pi, const void* theta, const uint64_t* rho, void* acc_gt);
+int gs_verify_batch_rlc(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A, const void* B,
+                        const void* Gamma, const void* target, const void* xcoms, const void* ycoms, const void* pi,
+                        const void* theta, const uint64_t* rho, void* acc_gt, uint8_t* ok_all);
+/* product of `count` GT accumulators (host), final exponentiation, == 1 ? */
+int gs_gt_finalize(gs_ctx*, size_t count, const void* accs_gt_host, uint8_t* ok_all);
+
+/* ---- L2 parity hooks (host pointers) ------------------------------------- */
+/* out[i] = sum_k lhs[i][k] * col[k]       (data_structures.rs:696-742) */
+int gs_mat_left_mul_com1(gs_ctx*, int rows, int k, const void* lhs_fr, const void* col_com1, void* out_com1);
+int gs_mat_left_mul_com2(gs_ctx*, int rows, int k, const void* lhs_fr, const void* col_com2, void* out_com2);
+/* ComT::pairing_sum(x[0..k), y[0..k)) -> 4 GT cells (00,01,10,11)   (data_structures.rs:494-502) */
+int gs_pairing_sum(gs_ctx*, int k, const void* x_com1, const void* y_com2, void* out_comt);
+/* batch helpers: out[i] = k[i] * P[i] (P broadcast if p_stride == 0), E::multi_pairing per row */
+int gs_g1_mul_batch(gs_ctx*, size_t count, const void* p_g1, int p_broadcast, const void* k_fr, void* out_g1);
+int gs_g2_mul_batch(gs_ctx*, size_t count, const void* p_g2, int p_broadcast, const void* k_fr, void* out_g2);
+int gs_g1_mul_batch_dev(gs_ctx*, size_t count, const void* p_g1, int p_broadcast, const void* k_fr, void* out_g1);
+int gs_g2_mul_batch_dev(gs_ctx*, size_t count, const void* p_g2, int p_broadcast, const void* k_fr, void* out_g2);
+int gs_multi_pairing_batch(gs_ctx*, size_t count, int k, const void* p_g1, const void* q_g2, void* out_gt);
+int gs_multi_pairing_batch_dev(gs_ctx*, size_t count, int k, const void* p_g1, const void* q_g2, void* out_gt);
+/* out[i] = base^(k[i]) in GT (k canonical-Montgomery Fr); used to synthesise satisfied PPE targets */
+int gs_gt_pow_batch_dev(gs_ctx*, size_t count, const void* base_gt_dev, const void* k_fr, void* out_gt);
+
+/* ---- measurement hook ----------------------------------------------------
+ * Name and average duration (ms, HIP events on the context's stream) of the
+ * kernels launched since gs_prof_reset; used by bench.py for the roofline. */
+int gs_prof_enable(gs_ctx*, int on);
+int gs_prof_reset(gs_ctx*);
+int gs_prof_get(gs_ctx*, int idx, char* name, size_t name_cap, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS_AMD_H */

@@ -1,0 +1,129 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the golden
+fixtures produced by the big-integer oracle (tests/golden/*.json).  Statements
+follow the reference's own tests (tests/prover.rs:25-172)."""
+import numpy as np
+import pytest
+
+from gsutil import curve
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines():
+    import groth_sahai_rs_amd as gs
+
+    out = {}
+    for cname, cid in (("bls12_381", 0), ("bn254", 1)):
+        c = curve(cname)
+        e = gs.Engine(cid, 0)
+        g = c.golden["crs"]
+        crs = np.concatenate([c.com1(g["u"][0]), c.com1(g["u"][1]), c.com2(g["v"][0]), c.com2(g["v"][1]),
+                              c.g1(g["g1"]), c.g2(g["g2"]), c.f12(g["gt"])])
+        e.set_crs(crs)
+        out[cname] = (c, e)
+    return out
+
+
+CURVES = ["bls12_381", "bn254"]
+
+
+def enc_side(c, ty, side, vals):
+    xg = ty in (0, 1)
+    yg = ty in (0, 2)
+    if side == "x":
+        return np.concatenate([c.g1(v) if xg else c.fr_hex(v) for v in vals])
+    return np.concatenate([c.g2(v) if yg else c.fr_hex(v) for v in vals])
+
+
+def enc_target(c, ty, t):
+    return {0: c.f12, 1: c.g1, 2: c.g2, 3: c.fr_hex}[ty](t)
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_smul_and_pairing_hooks(engines, cname):
+    c, e = engines[cname]
+    g = c.golden
+    g1 = c.g1(g["g1_smul"][0]["out"])
+    g2 = c.g2(g["g2_smul"][0]["out"])
+    ks = np.stack([c.fr_hex(x["k"]) for x in g["g1_smul"]] + [c.fr(0)])
+    o1 = e.g_mul_batch(1, g1, ks, broadcast=True)
+    o2 = e.g_mul_batch(2, g2, ks, broadcast=True)
+    for i, x in enumerate(g["g1_smul"]):
+        assert c.g1_dec(o1[i].view(np.uint64)) == x["out"]
+        assert c.g2_dec(o2[i].view(np.uint64)) == g["g2_smul"][i]["out"]
+    assert not o1[-1].any() and not o2[-1].any()
+    for pe in g["pairing"]:
+        out = e.multi_pairing_batch(1, 1, c.g1(pe["p"]), c.g2(pe["q"]))
+        assert c.f12_dec(out[0].view(np.uint64)) == pe["out"]
+    ps = g["pairing_sum"]
+    x = np.concatenate([c.com1(v) for v in ps["x"]])
+    y = np.concatenate([c.com2(v) for v in ps["y"]])
+    out = e.pairing_sum(len(ps["x"]), x, y)
+    for cell in range(4):
+        assert c.f12_dec(out[cell].view(np.uint64)) == ps["out"][cell], cell
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_left_mul_hook(engines, cname):
+    c, e = engines[cname]
+    lm = c.golden["left_mul"]
+    lhs = c.fr_mat(lm["lhs"])
+    rows, k = len(lm["lhs"]), len(lm["lhs"][0])
+    o1 = e.mat_left_mul(1, rows, k, lhs, np.concatenate([c.com1(v) for v in lm["com1"]]))
+    o2 = e.mat_left_mul(2, rows, k, lhs, np.concatenate([c.com2(v) for v in lm["com2"]]))
+    for i in range(rows):
+        got1 = o1[i].view(np.uint64).reshape(2, -1)
+        got2 = o2[i].view(np.uint64).reshape(2, -1)
+        assert [c.g1_dec(got1[0]), c.g1_dec(got1[1])] == lm["out1"][i]
+        assert [c.g2_dec(got2[0]), c.g2_dec(got2[1])] == lm["out2"][i]
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_commit_prove_verify_golden(engines, cname):
+    """commit_and_prove bit-exact vs the oracle for every golden case, then
+    verify == oracle verdict, then the negative twins."""
+    c, e = engines[cname]
+    for case in c.golden["cases"]:
+        ty, m, n = case["type"], case["m"], case["n"]
+        X = enc_side(c, ty, "x", case["xvars"])
+        Y = enc_side(c, ty, "y", case["yvars"])
+        A = enc_side(c, ty, "x", case["a"])
+        B = enc_side(c, ty, "y", case["b"])
+        G = c.fr_mat(case["gamma"])
+        R, S, T = c.fr_mat(case["R"]), c.fr_mat(case["S"]), c.fr_mat(case["T"])
+        out = e.prove_batch(ty, 1, m, n, X, Y, A, B, G, R, S, T, want_coms=True)
+        xc = out["xcoms"].view(np.uint64).reshape(m, 2, -1)
+        yc = out["ycoms"].view(np.uint64).reshape(n, 2, -1)
+        pi = out["pi"].view(np.uint64).reshape(-1, 2, 4 * c.nq)
+        th = out["theta"].view(np.uint64).reshape(-1, 2, 2 * c.nq)
+        name = case["name"]
+        assert [[c.g1_dec(v[0]), c.g1_dec(v[1])] for v in xc] == case["xcoms"], name
+        assert [[c.g2_dec(v[0]), c.g2_dec(v[1])] for v in yc] == case["ycoms"], name
+        assert [[c.g2_dec(v[0]), c.g2_dec(v[1])] for v in pi] == case["pi"], name
+        assert [[c.g1_dec(v[0]), c.g1_dec(v[1])] for v in th] == case["theta"], name
+        # prove-only entry (xcoms/ycoms = NULL) gives the same proof
+        out2 = e.prove_batch(ty, 1, m, n, X, Y, A, B, G, R, S, T, want_coms=False)
+        assert (out2["pi"] == out["pi"]).all() and (out2["theta"] == out["theta"]).all()
+        if "verify" not in case:
+            continue
+        tgt = enc_target(c, ty, case["target"])
+        ok = e.verify_batch(ty, 1, m, n, A, B, G, tgt, out["xcoms"], out["ycoms"], out["pi"], out["theta"])
+        assert ok[0] == 1, name
+        # negative twins of the fixture: theta[0].1 += g1 ; pi[0].0 += g2
+        g1 = c.g1(c.golden["crs"]["g1"])
+        g2 = c.g2(c.golden["crs"]["g2"])
+        one = c.fr(1).reshape(1, -1)
+        # compute P + g via the smul hook on 2 points would need an add hook; corrupt limbs instead
+        bad = out["theta"].copy()
+        bad[c.nq * 8 * 2] ^= 1  # flip a bit of theta[0].1.x
+        ok = e.verify_batch(ty, 1, m, n, A, B, G, tgt, out["xcoms"], out["ycoms"], out["pi"], bad)
+        assert ok[0] == 0, name
+        bad = out["pi"].copy()
+        bad[3] ^= 0x10
+        ok = e.verify_batch(ty, 1, m, n, A, B, G, tgt, out["xcoms"], out["ycoms"], bad, out["theta"])
+        assert ok[0] == 0, name
+        bad = tgt.copy().view(np.uint8)
+        bad[0] ^= 1
+        ok = e.verify_batch(ty, 1, m, n, A, B, G, bad, out["xcoms"], out["ycoms"], out["pi"], out["theta"])
+        assert ok[0] == 0, name
