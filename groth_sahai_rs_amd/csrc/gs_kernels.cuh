@@ -18,6 +18,9 @@
 
 namespace gs {
 
+#ifndef GS_WPE
+#define GS_WPE 1
+#endif
 constexpr int MAX_ARR = 8;
 struct ArrTab {
   const uint8_t* base[MAX_ARR];
@@ -58,7 +61,7 @@ template <class T> __device__ __forceinline__ T ld(const uint8_t* p) { return *r
 // generic helpers
 // --------------------------------------------------------------------------
 template <class C, class F>
-__global__ void __launch_bounds__(64) k_smul_batch(size_t n, const Aff<F>* p, int broadcast, const Fr<C>* k,
+__global__ void __launch_bounds__(64, GS_WPE) k_smul_batch(size_t n, const Aff<F>* p, int broadcast, const Fr<C>* k,
                                                    Aff<F>* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -83,7 +86,7 @@ template <class C, class F> __global__ void k_crs_derive(Aff<F>* pts) {
 
 // window tables: tab[(b*32 + w)*256 + d] = d * 2^(8w) * base[b]   (d = 0 -> identity)
 template <class C, class F>
-__global__ void __launch_bounds__(64) k_build_tables(int nb, const Aff<F>* bases, Aff<F>* tab) {
+__global__ void __launch_bounds__(64, GS_WPE) k_build_tables(int nb, const Aff<F>* bases, Aff<F>* tab) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nb * 32 * 256) return;
   int d = (int)(i & 255), w = (int)((i >> 8) & 31), b = (int)(i >> 13);
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(64) k_build_tables(int nb, const Aff<F>* bases
 // Fr preparation for prove (one lane per equation)
 // --------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, GS_WPE)
     k_prep_prove(size_t N, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R, const Fr<C>* S,
                  const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm,
                  Fr<C>* pool) {
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(64)
 
 // Fr preparation for verify: Gamma (and scalar constants / target) -> canonical
 template <class C>
-__global__ void __launch_bounds__(64) k_prep_verify(size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as,
+__global__ void __launch_bounds__(64, GS_WPE) k_prep_verify(size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as,
                                                     const Fr<C>* bs, const Fr<C>* tq, PoolMap pm, Fr<C>* pool) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(64) k_prep_verify(size_t N, int m, int n, cons
 // linear-combination engine
 // --------------------------------------------------------------------------
 template <class C, class F>
-__global__ void __launch_bounds__(64) k_var(size_t total, int ntask, const VarTask* tasks, ArrTab arrs,
+__global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, const VarTask* tasks, ArrTab arrs,
                                             const Fr<C>* pool, int pool_n, Jac<F>* part, int nslots) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(64) k_var(size_t total, int ntask, const VarTa
 }
 
 template <class C, class F>
-__global__ void __launch_bounds__(64) k_fix(size_t total, int ntask, const FixTask* tasks, ArrTab arrs,
+__global__ void __launch_bounds__(64, GS_WPE) k_fix(size_t total, int ntask, const FixTask* tasks, ArrTab arrs,
                                             const Fr<C>* pool, int pool_n, const Aff<F>* tab, Jac<F>* part,
                                             int nslots) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,7 +219,7 @@ __global__ void __launch_bounds__(64) k_fix(size_t total, int ntask, const FixTa
 }
 
 template <class C, class F>
-__global__ void __launch_bounds__(64) k_red(size_t total, int ntask, const RedTask* tasks, const Jac<F>* part,
+__global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, const RedTask* tasks, const Jac<F>* part,
                                             int nslots, OutTab outs) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(64) k_red(size_t total, int ntask, const RedTa
 // pairing side
 // --------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(64) k_miller(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
+__global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
                                                ArrTab qarr, Fp12<C>* out) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(64) k_miller(size_t total, int ntask, const Mi
 // cell_begin[c]..cell_begin[c+1] = the Miller tasks of cell c.  mode 0: exact
 // check (FE, compare with 1 or the PPE target) -> cellok[e*4+c].
 template <class C>
-__global__ void __launch_bounds__(64) k_final(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4,
+__global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4,
                                               const Fp12<C>* mpart, const Fp12<C>* target, uint8_t* cellok) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * 4) return;
@@ -298,7 +301,7 @@ __global__ void k_and4(size_t N, const uint8_t* cellok, uint8_t* ok) {
 
 // E::multi_pairing per row: k pairs -> Miller product -> final exponentiation
 template <class C>
-__global__ void __launch_bounds__(64) k_multi_pairing(size_t n, int k, const Aff<Fq<C>>* P, const Aff<Fp2<C>>* Q,
+__global__ void __launch_bounds__(64, GS_WPE) k_multi_pairing(size_t n, int k, const Aff<Fq<C>>* P, const Aff<Fp2<C>>* Q,
                                                       Fp12<C>* out) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(64) k_multi_pairing(size_t n, int k, const Aff
 
 // out[i] = base^(k[i]) for base in GT (cyclotomic squarings are valid)
 template <class C>
-__global__ void __launch_bounds__(64) k_gt_pow(size_t n, const Fp12<C>* base, const Fr<C>* k, Fp12<C>* out) {
+__global__ void __launch_bounds__(64, GS_WPE) k_gt_pow(size_t n, const Fp12<C>* base, const Fr<C>* k, Fp12<C>* out) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   Fr<C> s = from_mont(k[g]);

@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's operator interface for the hot path, on
+top of the C ABI (same names, argument meaning and error behaviour):
+
+    CRS                                   src/generator.rs:35-42 (struct only; generation is out of scope)
+    Commit1 / Commit2 {coms, rand}        src/prover/commit.rs:18-28
+    batch_commit_G1 / _G2 / _scalar_to_B1 / _scalar_to_B2, commit_G1 ...   commit.rs:59-256
+    PPE / MSMEG1 / MSMEG2 / QuadEqu {a_consts, b_consts, gamma, target}     src/statement.rs:117-192
+        .commit_and_prove(xvars, yvars, crs, rng) -> CProof                src/prover/prove.rs:29-52
+        .prove(xvars, yvars, xcoms, ycoms, crs, rng) -> EquProof
+        .verify(com_proof, crs) -> bool                                    src/verifier.rs:18-21
+    EquProof {pi, theta, equ_type, rand}, CProof {xcoms, ycoms, equ_proofs} prove.rs:55-69
+
+Values are numpy uint64 limb arrays in the boundary layout of include/gs_amd.h
+(G1 = 2*NQ limbs, G2 = 4*NQ, Fr = 4, GT = 12*NQ); lists of them where the
+reference has Vec<..>.  `rng` is any object with a method fr() returning one
+Montgomery-form scalar (4 u64 limbs); draws happen in the reference's order
+(R row-major, then S, then T: commit.rs:85-88,185-188; prove.rs:123-126).
+Shape mismatches raise AssertionError where the reference panics via
+assert_eq! (prove.rs:106-113; verifier.rs:25-26).
+
+The batched entry points (`prove_many` / `verify_many`) are the build's
+addition: N independent equations of one shape over the shared CRS -- the
+reference has no batch API.
+"""
+import numpy as np
+
+from .capi import GS_MSMEG1, GS_MSMEG2, GS_PPE, GS_QUAD, Engine
+
+
+class CRS:
+    """u: [Com1;2], v: [Com2;2], g1_gen, g2_gen, gt_gen  (generator.rs:35-42)."""
+
+    def __init__(self, u, v, g1_gen, g2_gen, gt_gen, curve=0, device=0):
+        self.u, self.v, self.g1_gen, self.g2_gen, self.gt_gen = u, v, g1_gen, g2_gen, gt_gen
+        self.engine = Engine(curve, device)
+        flat = np.concatenate([np.asarray(x, dtype=np.uint64).reshape(-1) for x in (u[0], u[1], v[0], v[1], g1_gen,
+                                                                                   g2_gen, gt_gen)])
+        self.engine.set_crs(flat)
+
+
+class Commit1:
+    def __init__(self, coms, rand):
+        self.coms, self.rand = coms, rand  # coms: list of Com1 (4*NQ limbs); rand: Matrix<Fr>
+
+    def __eq__(self, o):
+        return all((a == b).all() for a, b in zip(self.coms, o.coms)) and _mat_eq(self.rand, o.rand)
+
+    def append(self, other):  # commit.rs:43-51
+        assert len(self.coms) == len(self.rand) and len(other.coms) == len(other.rand)
+        self.coms += other.coms
+        self.rand += other.rand
+        other.coms, other.rand = [], []
+
+
+class Commit2(Commit1):
+    pass
+
+
+def _mat_eq(a, b):
+    return len(a) == len(b) and all(len(x) == len(y) and all((p == q).all() for p, q in zip(x, y)) for x, y in zip(a, b))
+
+
+def _cat(xs, width):
+    if len(xs) == 0:
+        return np.zeros(0, dtype=np.uint64)
+    return np.concatenate([np.asarray(x, dtype=np.uint64).reshape(-1) for x in xs])
+
+
+def _flat_mat(m):
+    return _cat([e for row in m for e in row], 4)
+
+
+def _split(buf, n):
+    a = np.asarray(buf).view(np.uint64)
+    return [a[i * (a.size // n):(i + 1) * (a.size // n)].copy() for i in range(n)] if n else []
+
+
+def _batch_commit(kind, vars_, key, rng, cols):
+    n = len(vars_)
+    rand = [[rng.fr() for _ in range(cols)] for _ in range(n)]
+    if n == 0:
+        return [], rand
+    out = key.engine.commit(kind, _cat(vars_, 0), _flat_mat(rand))
+    return [out[i].view(np.uint64).copy() for i in range(n)], rand
+
+
+def batch_commit_G1(xvars, key, rng):  # commit.rs:78-100
+    return Commit1(*_batch_commit("g1", xvars, key, rng, 2))
+
+
+def batch_commit_G2(yvars, key, rng):  # commit.rs:178-200
+    return Commit2(*_batch_commit("g2", yvars, key, rng, 2))
+
+
+def batch_commit_scalar_to_B1(scalar_xvars, key, rng):  # commit.rs:125-156
+    return Commit1(*_batch_commit("fr_b1", scalar_xvars, key, rng, 1))
+
+
+def batch_commit_scalar_to_B2(scalar_yvars, key, rng):  # commit.rs:225-256
+    return Commit2(*_batch_commit("fr_b2", scalar_yvars, key, rng, 1))
+
+
+def commit_G1(xvar, key, rng):  # commit.rs:59-75
+    return batch_commit_G1([xvar], key, rng)
+
+
+def commit_G2(yvar, key, rng):
+    return batch_commit_G2([yvar], key, rng)
+
+
+def commit_scalar_to_B1(x, key, rng):
+    return batch_commit_scalar_to_B1([x], key, rng)
+
+
+def commit_scalar_to_B2(y, key, rng):
+    return batch_commit_scalar_to_B2([y], key, rng)
+
+
+class EquProof:
+    def __init__(self, pi, theta, equ_type, rand):
+        self.pi, self.theta, self.equ_type, self.rand = pi, theta, equ_type, rand
+
+
+class CProof:
+    def __init__(self, xcoms, ycoms, equ_proofs):
+        self.xcoms, self.ycoms, self.equ_proofs = xcoms, ycoms, equ_proofs
+
+
+class _Equation:
+    TYPE = None
+
+    def __init__(self, a_consts, b_consts, gamma, target):
+        self.a_consts, self.b_consts, self.gamma, self.target = a_consts, b_consts, gamma, target
+
+    def get_type(self):
+        return self.TYPE
+
+    # -- Provable ---------------------------------------------------------
+    def _kxky(self):
+        return (2 if self.TYPE in (GS_PPE, GS_MSMEG1) else 1), (2 if self.TYPE in (GS_PPE, GS_MSMEG2) else 1)
+
+    def commit_and_prove(self, xvars, yvars, crs, rng):  # prove.rs:72-90 etc.
+        kx, ky = self._kxky()
+        xcoms = (batch_commit_G1 if kx == 2 else batch_commit_scalar_to_B1)(xvars, crs, rng)
+        ycoms = (batch_commit_G2 if ky == 2 else batch_commit_scalar_to_B2)(yvars, crs, rng)
+        return CProof(xcoms, ycoms, [self.prove(xvars, yvars, xcoms, ycoms, crs, rng)])
+
+    def prove(self, xvars, yvars, xcoms, ycoms, crs, rng):  # prove.rs:92-171 etc.
+        kx, ky = self._kxky()
+        # the reference's shape asserts (prove.rs:106-113)
+        assert len(xvars) == len(xcoms.rand)
+        assert len(self.gamma) == len(xcoms.rand)
+        assert len(xcoms.rand[0]) == kx
+        assert len(yvars) == len(ycoms.rand)
+        assert len(self.gamma[0]) == len(ycoms.rand)
+        assert len(ycoms.rand[0]) == ky
+        m, n = len(xvars), len(yvars)
+        T = [[rng.fr() for _ in range(kx)] for _ in range(ky)]
+        out = crs.engine.prove_batch(self.TYPE, 1, m, n, _cat(xvars, 0), _cat(yvars, 0), _cat(self.a_consts, 0),
+                                     _cat(self.b_consts, 0), _flat_mat(self.gamma), _flat_mat(xcoms.rand),
+                                     _flat_mat(ycoms.rand), _flat_mat(T), want_coms=False)
+        pi, theta = _split(out["pi"], kx), _split(out["theta"], ky)
+        assert len(pi) == kx and len(theta) == ky
+        return EquProof(pi, theta, self.TYPE, T)
+
+    # -- Verifiable --------------------------------------------------------
+    def verify(self, com_proof, crs):  # verifier.rs:23-157
+        assert len(com_proof.equ_proofs) == 1
+        assert self.get_type() == com_proof.equ_proofs[0].equ_type
+        pf = com_proof.equ_proofs[0]
+        m, n = len(com_proof.xcoms.coms), len(com_proof.ycoms.coms)
+        ok = crs.engine.verify_batch(self.TYPE, 1, m, n, _cat(self.a_consts, 0), _cat(self.b_consts, 0),
+                                     _flat_mat(self.gamma), np.asarray(self.target, dtype=np.uint64),
+                                     _cat(com_proof.xcoms.coms, 0), _cat(com_proof.ycoms.coms, 0), _cat(pf.pi, 0),
+                                     _cat(pf.theta, 0))
+        return bool(ok[0])
+
+
+class PPE(_Equation):
+    TYPE = GS_PPE
+
+
+class MSMEG1(_Equation):
+    TYPE = GS_MSMEG1
+
+
+class MSMEG2(_Equation):
+    TYPE = GS_MSMEG2
+
+
+class QuadEqu(_Equation):
+    TYPE = GS_QUAD

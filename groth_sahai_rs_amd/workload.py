@@ -40,7 +40,7 @@ CURVES = {
 
 
 class SplitMix64:
-    """Same generator as oracle/gs_oracle.py and oracle/gs_ref.c (seed = 20241220 + config)."""
+    """splitmix64 (seed = 20241220 + config index)."""
 
     def __init__(self, seed):
         self.s = seed & 0xFFFFFFFFFFFFFFFF

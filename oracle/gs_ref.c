@@ -46,11 +46,17 @@ typedef unsigned __int128 u128;
 typedef struct { u64 l[NL]; } fp;
 typedef struct { u64 l[4]; } fr;
 
-static void mont_mul_n(u64* r, const u64* a, const u64* b, const u64* mod, u64 inv, int n) {
+/* CIOS Montgomery product; `n` is a compile-time constant at every call site
+ * (always_inline + full unrolling), u128 accumulators -> mulx/adcx-class code. */
+static inline __attribute__((always_inline)) void mont_mul_n(u64* r, const u64* a, const u64* b, const u64* mod,
+                                                             u64 inv, const int n) {
   u64 t[8 + 2];
-  memset(t, 0, sizeof t);
+#pragma GCC unroll 10
+  for (int i = 0; i < n + 2; i++) t[i] = 0;
+#pragma GCC unroll 8
   for (int i = 0; i < n; i++) {
     u128 c = 0;
+#pragma GCC unroll 8
     for (int j = 0; j < n; j++) {
       c += (u128)a[j] * b[i] + t[j];
       t[j] = (u64)c;
@@ -62,6 +68,7 @@ static void mont_mul_n(u64* r, const u64* a, const u64* b, const u64* mod, u64 i
     u64 m = t[0] * inv;
     c = (u128)m * mod[0] + t[0];
     c >>= 64;
+#pragma GCC unroll 8
     for (int j = 1; j < n; j++) {
       c += (u128)m * mod[j] + t[j];
       t[j - 1] = (u64)c;
@@ -73,15 +80,17 @@ static void mont_mul_n(u64* r, const u64* a, const u64* b, const u64* mod, u64 i
   }
   u64 d[8];
   u64 br = 0;
+#pragma GCC unroll 8
   for (int j = 0; j < n; j++) {
     u128 s = (u128)t[j] - mod[j] - br;
     d[j] = (u64)s;
     br = (u64)(s >> 127);
   }
   int keep = (t[n] == 0) && br;
+#pragma GCC unroll 8
   for (int j = 0; j < n; j++) r[j] = keep ? t[j] : d[j];
 }
-static void add_n(u64* r, const u64* a, const u64* b, const u64* mod, int n) {
+static inline __attribute__((always_inline)) void add_n(u64* r, const u64* a, const u64* b, const u64* mod, int n) {
   u64 s[8], d[8];
   u64 c = 0, br = 0;
   for (int j = 0; j < n; j++) {
@@ -97,7 +106,7 @@ static void add_n(u64* r, const u64* a, const u64* b, const u64* mod, int n) {
   int keep = br && !c;
   for (int j = 0; j < n; j++) r[j] = keep ? s[j] : d[j];
 }
-static void sub_n(u64* r, const u64* a, const u64* b, const u64* mod, int n) {
+static inline __attribute__((always_inline)) void sub_n(u64* r, const u64* a, const u64* b, const u64* mod, int n) {
   u64 d[8];
   u64 br = 0, c = 0;
   for (int j = 0; j < n; j++) {

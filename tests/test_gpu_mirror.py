@@ -1,0 +1,127 @@
+"""The reference's own tests, restated against the host-side mirror of its API
+(groth_sahai_rs_amd/mirror.py) running on the GPU:
+  * tests/prover.rs:25-172      verify(commit_and_prove(..)) == true, 4 equation types
+  * commit.rs:440-548           batch commit == sequence of single commits under a synchronised RNG
+  * prove.rs:538-589 (+3 more)  commit_and_prove == batch_commit_* + prove under re-synchronised RNGs
+  * prove.rs:510-536            proof type tags
+  * statement shape asserts     prove.rs:106-113
+The replay RNG returns the fixture's recorded draws, which pins the draw order
+R (row-major), S, T."""
+import numpy as np
+import pytest
+
+from gsutil import curve
+
+pytestmark = pytest.mark.gpu
+
+
+class ReplayRng:
+    """Hands out recorded Montgomery-form scalars in order (stands in for `&mut CR: Rng`)."""
+
+    def __init__(self, c, mats):
+        self.q = [c.fr_hex(s) for m in mats for row in m for s in row]
+        self.i = 0
+
+    def fr(self):
+        v = self.q[self.i]
+        self.i += 1
+        return v
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from groth_sahai_rs_amd import mirror
+
+    c = curve("bls12_381")
+    g = c.golden["crs"]
+    crs = mirror.CRS([c.com1(g["u"][0]), c.com1(g["u"][1])], [c.com2(g["v"][0]), c.com2(g["v"][1])], c.g1(g["g1"]),
+                     c.g2(g["g2"]), c.f12(g["gt"]))
+    return c, mirror, crs
+
+
+def build(c, mirror, case):
+    ty = case["type"]
+    xg, yg = ty in (0, 1), ty in (0, 2)
+    ex = (lambda v: c.g1(v)) if xg else c.fr_hex
+    ey = (lambda v: c.g2(v)) if yg else c.fr_hex
+    cls = [mirror.PPE, mirror.MSMEG1, mirror.MSMEG2, mirror.QuadEqu][ty]
+    tgt = {0: c.f12, 1: c.g1, 2: c.g2, 3: c.fr_hex}[ty](case["target"])
+    equ = cls([ex(v) for v in case["a"]], [ey(v) for v in case["b"]], [[c.fr_hex(s) for s in row] for row in case["gamma"]],
+              tgt)
+    return equ, [ex(v) for v in case["xvars"]], [ey(v) for v in case["yvars"]]
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_equation_verifies(setup, idx):
+    """tests/prover.rs: X=[2g,3g], Y=[4g], Gamma=[[5],[0]], A=[c1], B=[O,c2] for each type."""
+    c, mirror, crs = setup
+    case = c.golden["cases"][idx]
+    equ, xvars, yvars = build(c, mirror, case)
+    rng = ReplayRng(c, [case["R"], case["S"], case["T"]])
+    proof = equ.commit_and_prove(xvars, yvars, crs, rng)
+    assert rng.i == len(rng.q)  # every draw consumed, in order
+    assert proof.equ_proofs[0].equ_type == equ.get_type() == case["type"]
+    pi = [[c.g2_dec(v.reshape(2, -1)[0]), c.g2_dec(v.reshape(2, -1)[1])] for v in proof.equ_proofs[0].pi]
+    th = [[c.g1_dec(v.reshape(2, -1)[0]), c.g1_dec(v.reshape(2, -1)[1])] for v in proof.equ_proofs[0].theta]
+    assert pi == case["pi"] and th == case["theta"]
+    assert equ.verify(proof, crs)
+
+
+def test_batch_commit_equals_single_commits(setup):
+    """commit.rs:440-548: same draws => batch == sequence of singles, for all four commit kinds."""
+    c, mirror, crs = setup
+    case = c.golden["cases"][4]  # dense PPE 2x2
+    _, xvars, yvars = build(c, mirror, case)
+    for batch, single, vars_, mat in [(mirror.batch_commit_G1, mirror.commit_G1, xvars, case["R"]),
+                                      (mirror.batch_commit_G2, mirror.commit_G2, yvars, case["S"])]:
+        b = batch(vars_, crs, ReplayRng(c, [mat]))
+        rng = ReplayRng(c, [mat])
+        acc = single(vars_[0], crs, rng)
+        for v in vars_[1:]:
+            acc.append(single(v, crs, rng))
+        assert b == acc
+    sc = c.golden["cases"][7]  # dense Quad 2x2: scalar variables on both sides
+    _, xs, ys = build(c, mirror, sc)
+    for batch, single, vars_, mat in [(mirror.batch_commit_scalar_to_B1, mirror.commit_scalar_to_B1, xs, sc["R"]),
+                                      (mirror.batch_commit_scalar_to_B2, mirror.commit_scalar_to_B2, ys, sc["S"])]:
+        b = batch(vars_, crs, ReplayRng(c, [mat]))
+        rng = ReplayRng(c, [mat])
+        acc = single(vars_[0], crs, rng)
+        for v in vars_[1:]:
+            acc.append(single(v, crs, rng))
+        assert b == acc
+
+
+@pytest.mark.parametrize("idx", [4, 5, 6, 7])
+def test_commit_and_prove_equals_commit_then_prove(setup, idx):
+    """prove.rs:538-589,653-702,764-813,880-932."""
+    c, mirror, crs = setup
+    case = c.golden["cases"][idx]
+    equ, xvars, yvars = build(c, mirror, case)
+    p1 = equ.commit_and_prove(xvars, yvars, crs, ReplayRng(c, [case["R"], case["S"], case["T"]]))
+    rng = ReplayRng(c, [case["R"], case["S"], case["T"]])
+    kx, ky = equ._kxky()
+    xc = (mirror.batch_commit_G1 if kx == 2 else mirror.batch_commit_scalar_to_B1)(xvars, crs, rng)
+    yc = (mirror.batch_commit_G2 if ky == 2 else mirror.batch_commit_scalar_to_B2)(yvars, crs, rng)
+    pf = equ.prove(xvars, yvars, xc, yc, crs, rng)
+    assert p1.xcoms == xc and p1.ycoms == yc
+    assert all((a == b).all() for a, b in zip(p1.equ_proofs[0].pi, pf.pi))
+    assert all((a == b).all() for a, b in zip(p1.equ_proofs[0].theta, pf.theta))
+
+
+def test_shape_asserts(setup):
+    """Shape mismatches panic in the reference (prove.rs:106-113); here: AssertionError / GS_ERR_SHAPE."""
+    import groth_sahai_rs_amd as gs
+
+    c, mirror, crs = setup
+    case = c.golden["cases"][0]
+    equ, xvars, yvars = build(c, mirror, case)
+    rng = ReplayRng(c, [case["R"], case["S"], case["T"], case["R"]])
+    xc = mirror.batch_commit_G1(xvars, crs, rng)
+    yc = mirror.batch_commit_G2(yvars, crs, rng)
+    with pytest.raises(AssertionError):
+        equ.prove(xvars[:1], yvars, xc, yc, crs, rng)  # xvars.len() != xcoms.rand.len()
+    with pytest.raises(gs.GsError) as ei:
+        crs.engine.prove_batch(0, 1, 0, 1, np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(1),
+                               np.zeros(1), np.zeros(1))
+    assert ei.value.code == 1  # GS_ERR_SHAPE: empty variable list (reference panics indexing rand[0])
