@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--n", type=int, default=4)
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--type", type=int, default=0)
+    ap.add_argument("--mode", choices=["exact", "rlc"], default="exact",
+                    help="verifier: exact = reference semantics (bool per equation); rlc = batched pairing-product check")
+    ap.add_argument("--mixed", action="store_true", help="configs[2]: 50%% PPE, 25%% MSMEG1, 25%% MSMEG2")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU-baseline sample units (0 = auto, ~20 s)")
     args = ap.parse_args()
@@ -78,7 +81,31 @@ def main():
     N = 1 << args.log2n
 
     eng = gs.Engine(args.curve, local)
-    wl = Workload(eng, ty=args.type, N=N, m=args.m, n=args.n, seed=20241220 + 1 + rank, device=dev)
+    if args.mixed:
+        # one CRS, three sub-batches (the engine runs one type/shape per call)
+        wls = [Workload(eng, ty=0, N=N // 2, m=args.m, n=args.n, seed=20241220 + 2 + rank, device=dev)]
+        crs = wls[0].crs
+        for ty in (1, 2):
+            wls.append(Workload(eng, ty=ty, N=N // 4, m=args.m, n=args.n, seed=20241220 + 2 + rank, device=dev))
+            assert (wls[-1].crs == crs).all()
+    else:
+        wls = [Workload(eng, ty=args.type, N=N, m=args.m, n=args.n, seed=20241220 + 1 + rank, device=dev)]
+    wl = wls[0]
+    from groth_sahai_rs_amd.dist import allgather_accumulators
+
+    def one_step():
+        for w in wls:
+            w.prove()
+        if args.mode == "exact":
+            for w in wls:
+                w.verify()
+            return None
+        accs = [w.verify_rlc() for w in wls]
+        allacc = []
+        for a in accs:  # cross-GPU product of GT accumulators: all-gather (RCCL) + fixed-order local product
+            allacc += allgather_accumulators(a)
+        pairs = torch.cat(allacc).cpu().numpy()
+        return eng.gt_finalize(pairs)
 
     def barrier():
         if dist is not None:
@@ -86,11 +113,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        wl.step()
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step()
+        verdict = one_step()
+        if args.mode == "rlc":
+            assert verdict == 1, "batched verifier rejected a valid batch"
     eng.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -100,27 +129,30 @@ def main():
         dt = float(tt.item())
 
     # ---- correctness of what was timed: all valid proofs accepted, corrupted ones rejected
-    wl.prove()
-    bad = wl.corrupt()
-    wl.verify()
-    eng.sync()
-    ok = wl.ok.cpu().numpy()
-    expect = [0 if i in set(bad) else 1 for i in range(N)]
-    assert ok.tolist() == expect, "verification verdicts wrong on the benchmark batch"
+    for w in wls:
+        w.prove()
+        bad = set(w.corrupt())
+        w.verify()
+        eng.sync()
+        ok = w.ok.cpu().numpy()
+        expect = [0 if i in bad else 1 for i in range(w.N)]
+        assert ok.tolist() == expect, "verification verdicts wrong on the benchmark batch"
+        if args.mode == "rlc" and bad:
+            assert eng.gt_finalize(w.verify_rlc().cpu().numpy()) == 0, "batched verifier accepted a corrupted batch"
 
     # ---- roofline leg: per-kernel HIP-event timing of one more step (rank 0)
     roof = None
     if rank == 0:
         eng.prof_enable(True)
         eng.prof_reset()
-        wl.step()
+        one_step()
         eng.sync()
         prof = eng.prof_get()
         eng.prof_enable(False)
         tot = sum(p[1] for p in prof) or 1.0
         name, ms, launches = max(prof, key=lambda p: p[1])
         avg_s = ms / max(launches, 1) / 1e3
-        bpu = wl.bytes_per_unit()
+        bpu = sum(w.bytes_per_unit() * w.N for w in wls) / N
         achieved = N * bpu / avg_s / 1e9
         roof = {
             "bound": "hbm",
@@ -152,8 +184,9 @@ def main():
         "vs_baseline": None,
         "dtype": "u32 limbs (381-bit Montgomery)" if args.curve == 0 else "u32 limbs (254-bit Montgomery)",
         "data": "synthetic",
-        "config": {"workload": "2^%d independent %s equations per GPU, m=%d n=%d, commit_and_prove+verify(exact)"
-                   % (args.log2n, ["PPE", "MSMEG1", "MSMEG2", "QuadEqu"][args.type], args.m, args.n),
+        "config": {"workload": "2^%d independent %s equations per GPU, m=%d n=%d, commit_and_prove+verify(%s)"
+                   % (args.log2n, "mixed 50%% PPE/25%% MSMEG1/25%% MSMEG2" if args.mixed else
+                      ["PPE", "MSMEG1", "MSMEG2", "QuadEqu"][args.type], args.m, args.n, args.mode),
                    "curve": "BLS12-381" if args.curve == 0 else "BN254", "equations_per_gpu": N,
                    "parallelism": "equation-sharded x%d" % world},
     }

@@ -155,6 +155,26 @@ class Engine:
                                            _p(u8(theta)), _p(ok)))
         return ok
 
+    def verify_batch_rlc(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, rho):
+        """Batched verifier (host buffers).  rho: uint64[N*4].  Returns (ok_all, acc_pair_bytes)."""
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        rho = np.ascontiguousarray(rho, dtype=np.uint64).reshape(-1)
+        assert rho.size == 4 * N
+        acc = self._out(2 * self.GT)
+        ok = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.gs_verify_batch_rlc(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(A)), _p(u8(B)),
+                                               _p(u8(Gamma)), _p(u8(target)), _p(u8(xcoms)), _p(u8(ycoms)),
+                                               _p(u8(pi)), _p(u8(theta)), _p(rho), _p(acc), _p(ok)))
+        return int(ok[0]), acc
+
+    def gt_finalize(self, accs):
+        """accs: bytes of `count` accumulator pairs (host).  FE(prod acc[i][0]) == prod acc[i][1] ?"""
+        a = np.ascontiguousarray(accs).view(np.uint8).reshape(-1)
+        count = a.size // (2 * self.GT)
+        ok = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.gs_gt_finalize(self.ctx, ctypes.c_size_t(count), _p(a), _p(ok)))
+        return int(ok[0])
+
     def mat_left_mul(self, group, rows, k, lhs, col):
         fn = self.lib.gs_mat_left_mul_com1 if group == 1 else self.lib.gs_mat_left_mul_com2
         osz = self.COM1 if group == 1 else self.COM2
@@ -194,6 +214,11 @@ class Engine:
     def verify_batch_dev(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, ok):
         self._chk(self.lib.gs_verify_batch_dev(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(A), _p(B), _p(Gamma),
                                                _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(ok)))
+
+    def verify_batch_rlc_dev(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, rho, acc):
+        self._chk(self.lib.gs_verify_batch_rlc_dev(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(A), _p(B), _p(Gamma),
+                                                   _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(rho),
+                                                   _p(acc)))
 
     def g_mul_batch_dev(self, group, n, points, broadcast, scalars, out):
         fn = self.lib.gs_g1_mul_batch_dev if group == 1 else self.lib.gs_g2_mul_batch_dev

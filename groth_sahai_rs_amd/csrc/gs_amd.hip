@@ -495,9 +495,10 @@ template <class C> struct Impl {
     vp.cb[4] = (int)vp.mt.size();
   }
 
-  static int verify(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
-                    const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
-                    uint8_t* ok) {
+  // shared front of both verifier modes: G1-side points + Miller partials
+  static int verify_front(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                          const void* target, const void* xcoms, const void* ycoms, const void* pi,
+                          const void* theta, VerifyPlan& vp, void** mpart_out) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
     int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     PoolMap pm;
@@ -512,7 +513,6 @@ template <class C> struct Impl {
     RC(scratch(c, "verify.pool", N * pm.total * sizeof(S), &pool));
     RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, (const S*)G, xg ? nullptr : (const S*)A,
               yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm, (S*)pool));
-    VerifyPlan vp;
     build_verify(vp, ty, m, n, pm);
     // G1-side points
     void* pa;
@@ -564,11 +564,85 @@ template <class C> struct Impl {
     qarr.base[4] = (const uint8_t*)target;
     qarr.stride[4] = (uint32_t)sizeof(A2);
     RC(launch(c, "k_miller", k_miller<C>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
+    *mpart_out = mpart;
+    return GS_OK;
+  }
+
+  static int verify(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                    const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                    uint8_t* ok) {
+    VerifyPlan vp;
+    void* mpart;
+    RC(verify_front(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, vp, &mpart));
+    int ntask = (int)vp.mt.size();
     void* cellok;
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
     RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cb[0], vp.cb[1], vp.cb[2], vp.cb[3], vp.cb[4],
               (const GT*)mpart, ty == GS_PPE ? (const GT*)target : nullptr, (uint8_t*)cellok));
     RC(launch(c, "k_and4", k_and4, N, 256, N, (const uint8_t*)cellok, ok));
+    return GS_OK;
+  }
+
+  // product of n GT elements at `buf` (clobbers buf/tmp), result copied to dst[0]
+  static int gt_product(gs_ctx* c, size_t n, GT* buf, GT* tmp, GT* dst) {
+    const int K = 8;
+    GT *in = buf, *out = tmp;
+    while (n > 1) {
+      size_t no = (n + K - 1) / K;
+      RC(launch(c, "k_gt_prod", k_gt_prod<C>, no, 64, n, (const GT*)in, no, out, K));
+      GT* t = in;
+      in = out;
+      out = t;
+      n = no;
+    }
+    HIPCHK(c, hipMemcpyAsync(dst, in, sizeof(GT), hipMemcpyDeviceToDevice, c->stream));
+    return GS_OK;
+  }
+
+  // batched verifier: acc[0] = prod_{e,cell} Miller(e,cell)^rho, acc[1] = prod_e t_e^rho (1 for non-PPE)
+  static int verify_rlc(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                        const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                        const uint64_t* rho, void* acc) {
+    VerifyPlan vp;
+    void* mpart;
+    RC(verify_front(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, vp, &mpart));
+    int ntask = (int)vp.mt.size();
+    void *pf, *pt, *tmp;
+    RC(scratch(c, "rlc.f", N * 4 * sizeof(GT), &pf));
+    RC(scratch(c, "rlc.t", N * sizeof(GT), &pt));
+    RC(scratch(c, "rlc.tmp", (N / 2 + 8) * sizeof(GT), &tmp));
+    RC(launch(c, "k_rlc_pow", k_rlc_pow<C>, N * 4, 64, N, ntask, vp.cb[0], vp.cb[1], vp.cb[2], vp.cb[3], vp.cb[4],
+              (const GT*)mpart, ty == GS_PPE ? (const GT*)target : nullptr, rho, (GT*)pf, (GT*)pt));
+    GT* a = (GT*)acc;
+    RC(gt_product(c, N * 4, (GT*)pf, (GT*)tmp, a));
+    if (ty == GS_PPE)
+      RC(gt_product(c, N, (GT*)pt, (GT*)tmp, a + 1));
+    else
+      RC(launch(c, "k_gt_set_one", k_gt_set_one<C>, 1, 64, a + 1));
+    return GS_OK;
+  }
+
+  // accs: count pairs (host).  ok = FE(prod accs[i][0]) == prod accs[i][1]
+  static int gt_finalize(gs_ctx* c, size_t count, const void* accs_host, uint8_t* ok_host) {
+    void *d, *t, *two, *dok;
+    RC(scratch(c, "fin.in", 2 * count * sizeof(GT), &d));
+    RC(scratch(c, "fin.tmp", (count + 8) * sizeof(GT), &t));
+    RC(scratch(c, "fin.two", 2 * sizeof(GT), &two));
+    RC(scratch(c, "fin.ok", 16, &dok));
+    // de-interleave on the host: [f0 f1 ...][t0 t1 ...]
+    std::vector<uint8_t> h(2 * count * sizeof(GT));
+    const uint8_t* src = (const uint8_t*)accs_host;
+    for (size_t i = 0; i < count; i++) {
+      memcpy(&h[i * sizeof(GT)], src + (2 * i) * sizeof(GT), sizeof(GT));
+      memcpy(&h[(count + i) * sizeof(GT)], src + (2 * i + 1) * sizeof(GT), sizeof(GT));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice));
+    RC(gt_product(c, count, (GT*)d, (GT*)t, (GT*)two));
+    RC(gt_product(c, count, (GT*)d + count, (GT*)t, (GT*)two + 1));
+    RC(launch(c, "k_fe_eq", k_fe_eq<C>, 1, 64, (const GT*)two, (uint8_t*)dok));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(ok_host, dok, 1, hipMemcpyDeviceToHost));
     return GS_OK;
   }
 };
@@ -966,17 +1040,50 @@ int gs_mat_left_mul_com2(gs_ctx* c, int rows, int k, const void* lhs, const void
   return left_mul_impl<Bn254, Fp2<Bn254>>(c, rows, k, lhs, col, out);
 }
 
-// ---- RLC mode: implemented in a later milestone ---------------------------------
-int gs_verify_batch_rlc_dev(gs_ctx* c, int, size_t, int, int, const void*, const void*, const void*, const void*,
-                            const void*, const void*, const void*, const void*, const uint64_t*, void*) {
-  return fail(c, GS_ERR_ARG, "gs_verify_batch_rlc: not implemented yet");
+// ---- batched (RLC) verifier ---------------------------------------------------------
+int gs_verify_batch_rlc_dev(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                            const void* target, const void* xcoms, const void* ycoms, const void* pi,
+                            const void* theta, const uint64_t* rho, void* acc) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (!A || !B || !G || !target || !xcoms || !ycoms || !pi || !theta || !rho || !acc || N == 0)
+    return fail(c, GS_ERR_ARG, "null pointer or empty batch");
+  return DISPATCH(c, verify_rlc(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, rho, acc));
 }
-int gs_verify_batch_rlc(gs_ctx* c, int, size_t, int, int, const void*, const void*, const void*, const void*,
-                        const void*, const void*, const void*, const void*, const uint64_t*, void*, uint8_t*) {
-  return fail(c, GS_ERR_ARG, "gs_verify_batch_rlc: not implemented yet");
+int gs_verify_batch_rlc(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
+                        const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                        const uint64_t* rho, void* acc, uint8_t* ok_all) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (N == 0) return fail(c, GS_ERR_ARG, "empty batch");
+  size_t fq = sz_fq(c->curve);
+  bool xg = x_is_group(ty), yg = y_is_group(ty);
+  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
+  size_t st_ = ty == GS_PPE ? 12 * fq : ty == GS_MSMEG1 ? 2 * fq : ty == GS_MSMEG2 ? 4 * fq : SZ_FR;
+  HostStage st(c);
+  void *dA, *dB, *dG, *dt, *dxc, *dyc, *dpi, *dth, *drho, *dacc;
+  std::vector<uint8_t> hacc(2 * 12 * fq);
+  RC(st.in(A, N * n * sx, &dA));
+  RC(st.in(B, N * m * sy, &dB));
+  RC(st.in(G, N * m * n * SZ_FR, &dG));
+  RC(st.in(target, N * st_, &dt));
+  RC(st.in(xcoms, N * m * 4 * fq, &dxc));
+  RC(st.in(ycoms, N * n * 8 * fq, &dyc));
+  RC(st.in(pi, N * kx * 8 * fq, &dpi));
+  RC(st.in(theta, N * ky * 4 * fq, &dth));
+  RC(st.in(rho, N * 4 * sizeof(uint64_t), &drho));
+  RC(st.out(hacc.data(), hacc.size(), &dacc));
+  RC(gs_verify_batch_rlc_dev(c, ty, N, m, n, dA, dB, dG, dt, dxc, dyc, dpi, dth, (const uint64_t*)drho, dacc));
+  RC(st.back(hacc.data(), dacc, hacc.size()));
+  if (acc) memcpy(acc, hacc.data(), hacc.size());
+  if (ok_all) RC(gs_gt_finalize(c, 1, hacc.data(), ok_all));
+  return GS_OK;
 }
-int gs_gt_finalize(gs_ctx* c, size_t, const void*, uint8_t*) {
-  return fail(c, GS_ERR_ARG, "gs_gt_finalize: not implemented yet");
+int gs_gt_finalize(gs_ctx* c, size_t count, const void* accs, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  if (!accs || !ok || count == 0) return fail(c, GS_ERR_ARG, "null pointer");
+  return DISPATCH(c, gt_finalize(c, count, accs, ok));
 }
 
 // ---- profiling ---------------------------------------------------------------------

@@ -21,6 +21,8 @@
 #define GS_HD_NOINLINE __attribute__((noinline))
 #endif
 
+#include "gs_montmul_asm.h"
+
 namespace gs {
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
@@ -77,6 +79,24 @@ template <class M>
 GS_HD_NOINLINE typename Fe<M>::V mont_mul_raw(typename Fe<M>::V a, typename Fe<M>::V b) {
   constexpr int N = M::N;
   uint32_t t[N + 1];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM)
+  {
+    // hand-scheduled product-scanning kernel (gs_montmul_asm.h): 2 VALU ops per MAC
+    uint32_t av[N], bv[N], rv[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      av[i] = a[i];
+      bv[i] = b[i];
+    }
+    if constexpr (N == 12)
+      mont_mul_asm_12<M>(rv, av, bv);
+    else
+      mont_mul_asm_8<M>(rv, av, bv);
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = rv[i];
+    t[N] = 0;
+  }
+#else
 #pragma unroll
   for (int i = 0; i <= N; i++) t[i] = 0;
 #pragma unroll
@@ -102,6 +122,7 @@ GS_HD_NOINLINE typename Fe<M>::V mont_mul_raw(typename Fe<M>::V a, typename Fe<M
     t[N - 1] = (uint32_t)c;
     t[N] = (uint32_t)(c >> 32);
   }
+#endif
   // result < 2p: one conditional subtraction
   uint32_t d[N];
   uint32_t br = 0;

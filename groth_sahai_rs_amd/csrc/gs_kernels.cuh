@@ -346,4 +346,70 @@ __global__ void __launch_bounds__(64, GS_WPE) k_gt_pow(size_t n, const Fp12<C>* 
   out[g] = acc;
 }
 
+// ---- batched (random-linear-combination) verifier -------------------------------
+// lane (e, c): g = product of the cell's Miller partials (NOT exponentiated);
+// out_f[e*4+c] = g^rho[e*4+c]; for the PPE target cell also out_t[e] = t^rho.
+// The whole batch then needs ONE final exponentiation:  FE(prod out_f) == prod out_t.
+template <class C> GS_HD_NOINLINE void f12_pow_u64(Fp12<C>& r, const Fp12<C>& b, uint64_t k) {
+  Fp12<C> acc;
+  f12_one(acc);
+  bool started = false;
+  for (int i = 63; i >= 0; i--) {
+    if (started) f12_sqr(acc, acc);
+    if ((k >> i) & 1) {
+      if (started)
+        f12_mul(acc, acc, b);
+      else
+        acc = b;
+      started = true;
+    }
+  }
+  r = acc;
+}
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE)
+    k_rlc_pow(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4, const Fp12<C>* mpart,
+              const Fp12<C>* target, const uint64_t* rho, Fp12<C>* out_f, Fp12<C>* out_t) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * 4) return;
+  size_t e = g >> 2;
+  int c = (int)(g & 3);
+  int b = c == 0 ? cb0 : c == 1 ? cb1 : c == 2 ? cb2 : cb3;
+  int en = c == 0 ? cb1 : c == 1 ? cb2 : c == 2 ? cb3 : cb4;
+  Fp12<C> f = mpart[e * ntask + b];
+  for (int i = b + 1; i < en; i++) f12_mul(f, f, mpart[e * ntask + i]);
+  Fp12<C> h;
+  f12_pow_u64(h, f, rho[g]);
+  out_f[g] = h;
+  if (c == 3 && target) {
+    Fp12<C> t = target[e];
+    f12_pow_u64(h, t, rho[g]);
+    out_t[e] = h;
+  }
+}
+// out[i] = product of in[i*K .. min((i+1)*K, n_in))
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE) k_gt_prod(size_t n_in, const Fp12<C>* in, size_t n_out, Fp12<C>* out,
+                                                        int K) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_out) return;
+  size_t lo = g * (size_t)K, hi = lo + K < n_in ? lo + K : n_in;
+  Fp12<C> acc = in[lo];
+  for (size_t i = lo + 1; i < hi; i++) f12_mul(acc, acc, in[i]);
+  out[g] = acc;
+}
+// acc[0] = Miller-side accumulator, acc[1] = target-side accumulator: ok = (FE(acc[0]) == acc[1])
+template <class C> __global__ void k_fe_eq(const Fp12<C>* acc, uint8_t* ok) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Fp12<C> r;
+  final_exp(r, acc[0]);
+  ok[0] = f12_eq(r, acc[1]) ? 1 : 0;
+}
+template <class C> __global__ void k_gt_set_one(Fp12<C>* p) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Fp12<C> o;
+  f12_one(o);
+  p[0] = o;
+}
+
 }  // namespace gs

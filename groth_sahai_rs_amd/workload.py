@@ -209,6 +209,19 @@ class Workload:
         self.eng.verify_batch_dev(self.ty, self.N, self.m, self.n, self.A, self.B, self.Gamma, self.target,
                                   self.xcoms, self.ycoms, self.pi, self.theta, self.ok)
 
+    def verify_rlc(self):
+        """batched verifier: ONE final exponentiation for the batch; returns the accumulator pair (device)"""
+        import torch
+
+        if not hasattr(self, "rho"):
+            g = torch.Generator(device="cpu").manual_seed(20241220)
+            rho = torch.randint(1, 2**62, (self.N * 4,), generator=g, dtype=torch.int64)
+            self.rho = rho.to(self.xcoms.device)
+            self.acc = torch.empty(2 * self.eng.GT, dtype=torch.uint8, device=self.xcoms.device)
+        self.eng.verify_batch_rlc_dev(self.ty, self.N, self.m, self.n, self.A, self.B, self.Gamma, self.target,
+                                      self.xcoms, self.ycoms, self.pi, self.theta, self.rho, self.acc)
+        return self.acc
+
     def step(self):
         """one pass of the hot path over the batch: commit_and_prove then verify"""
         self.prove()

@@ -108,9 +108,11 @@ int gs_verify_batch(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A
 /* Batched pairing-product check: random linear combination of all 4N cell
  * equations with caller-supplied 64-bit exponents rho[N][4] (device/host u64),
  * one final exponentiation for the whole batch.  *ok_all = 1 iff the combined
- * check passes; acc (may be NULL) receives the un-exponentiated GT accumulator
- * (one GT) so that ranks can multiply accumulators before exponentiating:
- * gs_gt_finalize(prod of accs) gives the same verdict for the union. */
+ * check passes; acc (may be NULL for the host entry) receives the accumulator PAIR
+ * (2 GT): acc[0] = prod Miller(e,cell)^rho (un-exponentiated), acc[1] = prod t_e^rho
+ * (1 for the non-PPE types).  Ranks exchange their pairs (all-gather) and
+ * gs_gt_finalize(count, pairs) multiplies them in the given order and checks
+ * FE(prod acc[0]) == prod acc[1]: the verdict for the union of the batches. */
 int gs_verify_batch_rlc_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A, const void* B,
                             const void* Gamma, const void* target, const void* xcoms, const void* ycoms,
                             const void* pi, const void* theta, const uint64_t* rho, void* acc_gt);

@@ -127,3 +127,43 @@ def test_commit_prove_verify_golden(engines, cname):
         bad[0] ^= 1
         ok = e.verify_batch(ty, 1, m, n, A, B, G, bad, out["xcoms"], out["ycoms"], out["pi"], out["theta"])
         assert ok[0] == 0, name
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_rlc_batched_verifier(engines, cname):
+    """Batched (random-linear-combination) verifier: one final exponentiation per
+    batch.  Accepts iff every equation verifies; accumulators of sub-batches
+    multiply (what the multi-GPU path all-gathers)."""
+    c, e = engines[cname]
+    rng = np.random.default_rng(7)
+    for ty_cases in ([0, 4], [1, 5], [2, 6], [3, 7]):  # (ref 2x1, dense 2x2) of each type have different shapes
+        for idx in ty_cases:
+            case = c.golden["cases"][idx]
+            ty, m, n = case["type"], case["m"], case["n"]
+            X, Y = enc_side(c, ty, "x", case["xvars"]), enc_side(c, ty, "y", case["yvars"])
+            A, B = enc_side(c, ty, "x", case["a"]), enc_side(c, ty, "y", case["b"])
+            G, R, S, T = (c.fr_mat(case[k]) for k in ("gamma", "R", "S", "T"))
+            tgt = enc_target(c, ty, case["target"])
+            out = e.prove_batch(ty, 1, m, n, X, Y, A, B, G, R, S, T)
+            # batch of 3 copies of the same equation
+            rep = lambda a: np.concatenate([np.asarray(a).view(np.uint8).reshape(-1)] * 3)
+            args = [rep(A), rep(B), rep(G), rep(tgt), rep(out["xcoms"]), rep(out["ycoms"]), rep(out["pi"]),
+                    rep(out["theta"])]
+            rho = rng.integers(1, 1 << 63, size=12, dtype=np.uint64)
+            ok, acc = e.verify_batch_rlc(ty, 3, m, n, *args, rho)
+            assert ok == 1, case["name"]
+            # corrupt the middle proof: theta of equation 1
+            bad = args[7].copy()
+            bad[len(bad) // 3 + 7] ^= 2
+            ok2, _ = e.verify_batch_rlc(ty, 3, m, n, *args[:7], bad, rho)
+            assert ok2 == 0, case["name"]
+            # split: equations {0,1} and {2} on two "ranks": product of accumulators = same verdict
+            first = [a[: 2 * (a.size // 3)] for a in args]
+            last = [a[2 * (a.size // 3):] for a in args]
+            _, acc_a = e.verify_batch_rlc(ty, 2, m, n, *first, rho[:8])
+            _, acc_b = e.verify_batch_rlc(ty, 1, m, n, *last, rho[8:])
+            assert e.gt_finalize(np.concatenate([acc_a, acc_b])) == 1
+            bad_last = [a.copy() for a in last]
+            bad_last[6][3] ^= 1
+            _, acc_c = e.verify_batch_rlc(ty, 1, m, n, *bad_last, rho[8:])
+            assert e.gt_finalize(np.concatenate([acc_a, acc_c])) == 0
