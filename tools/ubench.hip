@@ -32,6 +32,12 @@ template <int OP> __global__ void kern(uint32_t* out, int iters, uint32_t seed) 
       REP16(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(d0), "+v"(d1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");)
     } else if (OP == 8) {  // v_mul_u32_u24 + v_mul_hi_u32_u24
       REP16(asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_hi_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_hi_u32_u24 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+    } else if (OP == 10) {  // ONE dependent chain: mad -> addc -> mad ... (the Comba inner step)
+      REP16(asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_addc_co_u32 %1, vcc, 0, %1, vcc\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(d0), "+v"(a2) : "v"(b), "v"(c) : "vcc");)
+    } else if (OP == 11) {  // ONE dependent chain of v_mad_u64_u32 only
+      REP16(asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d0) : "v"(b), "v"(c) : "vcc");)
+    } else if (OP == 12) {  // ONE dependent chain of v_add_u32
+      REP16(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1" : "+v"(a0) : "v"(b));)
     } else if (OP == 9) {  // v_add_u32 (full-rate reference)
       REP16(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
     }
@@ -66,7 +72,21 @@ template <int OP> void run(const char* name, uint32_t* d) {
   printf("\n");
 }
 
+__global__ void clk_probe(unsigned long long* out, int iters) {
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  uint32_t a = threadIdx.x, b = 12345;
+  for (int i = 0; i < iters; i++) { REP16(asm volatile("v_mad_u64_u32 v[100:101], vcc, %0, %1, v[100:101]" :: "v"(a), "v"(b) : "vcc", "v100", "v101");) }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
 int main() {
+  {
+    unsigned long long* o; hipMalloc(&o, 16);
+    hipLaunchKernelGGL(clk_probe, dim3(256 * 8), dim3(256), 0, 0, o, 200000);
+    hipDeviceSynchronize();
+    unsigned long long h[2]; hipMemcpy(h, o, 16, hipMemcpyDeviceToHost);
+    printf("in-kernel clock under integer load: %.3f GHz (s_memtime %llu / s_memrealtime %llu x 100 MHz)\n", (double)h[0] / (double)h[1] * 0.1, h[0], h[1]);
+  }
   uint32_t* d;
   hipMalloc(&d, 256 * 256 * 8 * 4 * 4);
   hipDeviceProp_t pr;
@@ -82,5 +102,8 @@ int main() {
   run<4>("v_fma_f64", d);
   run<5>("v_add_co/v_addc_co", d);
   run<6>("v_lshl_add_u64", d);
+  run<10>("dep chain mad+addc", d);
+  run<11>("dep chain mad only", d);
+  run<12>("dep chain v_add_u32", d);
   return 0;
 }
