@@ -121,7 +121,8 @@ static inline bool x_is_group(int ty) { return ty == GS_PPE || ty == GS_MSMEG1; 
 static inline bool y_is_group(int ty) { return ty == GS_PPE || ty == GS_MSMEG2; }
 
 template <class C> struct Sz {
-  static constexpr size_t FQ = sizeof(Fq<C>), FR = sizeof(Fr<C>), G1 = 2 * FQ, G2 = 4 * FQ, GT = 12 * FQ,
+  // BOUNDARY sizes (include/gs_amd.h), not the internal radix-2^28 structs
+  static constexpr size_t FQ = 4 * C::N, FR = sizeof(Fr<C>), G1 = 2 * FQ, G2 = 4 * FQ, GT = 12 * FQ,
                           COM1 = 2 * G1, COM2 = 2 * G2, CRS = 2 * COM1 + 2 * COM2 + G1 + G2 + GT;
 };
 
@@ -267,41 +268,43 @@ template <class C> struct Impl {
 
   static int set_crs(gs_ctx* c, const void* crs_host) {
     const uint8_t* h = (const uint8_t*)crs_host;
-    A1 g1pts[6];
-    A2 g2pts[6];
-    memcpy(&g1pts[0], h, 4 * sizeof(A1));                     // u0.0 u0.1 u1.0 u1.1
-    memcpy(&g2pts[0], h + 2 * Z::COM1, 4 * sizeof(A2));       // v0.0 v0.1 v1.0 v1.1
-    A1 g1;
-    A2 g2;
-    memcpy(&g1, h + 2 * Z::COM1 + 2 * Z::COM2, sizeof g1);
-    memcpy(&g2, h + 2 * Z::COM1 + 2 * Z::COM2 + Z::G1, sizeof g2);
-    // W1 = u[1] + (O, g1), W2 = v[1] + (O, g2)   (data_structures.rs:323-326, 368-371), derived on the device
-    g1pts[4] = g1pts[2];
-    g2pts[4] = g2pts[2];
-    g1pts[5] = g1;   // slot 5 holds the addend on the way in
-    g2pts[5] = g2;
-    RC(ensure(c, c->crs_g1, sizeof g1pts));
-    RC(ensure(c, c->crs_g2, sizeof g2pts));
-    HIPCHK(c, hipMemcpy(c->crs_g1.p, g1pts, sizeof g1pts, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->crs_g2.p, g2pts, sizeof g2pts, hipMemcpyHostToDevice));
-    RC(launch(c, "k_crs_derive.g1", k_crs_derive<C, F1>, 1, 64, (A1*)c->crs_g1.p));
-    RC(launch(c, "k_crs_derive.g2", k_crs_derive<C, F2>, 1, 64, (A2*)c->crs_g2.p));
+    // device copies (boundary form): 6 G1 points u0.0 u0.1 u1.0 u1.1 W1.0 W1.1, same for G2
+    std::vector<uint8_t> g1pts(6 * Z::G1), g2pts(6 * Z::G2);
+    memcpy(&g1pts[0], h, 4 * Z::G1);
+    memcpy(&g2pts[0], h + 2 * Z::COM1, 4 * Z::G2);
+    const uint8_t* g1 = h + 2 * Z::COM1 + 2 * Z::COM2;
+    const uint8_t* g2 = g1 + Z::G1;
+    // W1 = u[1] + (O, g1), W2 = v[1] + (O, g2)   (data_structures.rs:323-326, 368-371), derived on the device:
+    // slot 4 = u1.0, slot 5 holds the addend on the way in
+    memcpy(&g1pts[4 * Z::G1], &g1pts[2 * Z::G1], Z::G1);
+    memcpy(&g2pts[4 * Z::G2], &g2pts[2 * Z::G2], Z::G2);
+    memcpy(&g1pts[5 * Z::G1], g1, Z::G1);
+    memcpy(&g2pts[5 * Z::G2], g2, Z::G2);
+    RC(ensure(c, c->crs_g1, g1pts.size()));
+    RC(ensure(c, c->crs_g2, g2pts.size()));
+    HIPCHK(c, hipMemcpy(c->crs_g1.p, g1pts.data(), g1pts.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->crs_g2.p, g2pts.data(), g2pts.size(), hipMemcpyHostToDevice));
+    RC(launch(c, "k_crs_derive.g1", k_crs_derive<C, F1>, 1, 64, (uint8_t*)c->crs_g1.p));
+    RC(launch(c, "k_crs_derive.g2", k_crs_derive<C, F2>, 1, 64, (uint8_t*)c->crs_g2.p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(g1pts, c->crs_g1.p, sizeof g1pts, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g2pts, c->crs_g2.p, sizeof g2pts, hipMemcpyDeviceToHost));
-    // window tables for bases {u0.0,u0.1,u1.0,u1.1,W.1}
-    A1 b1[5] = {g1pts[0], g1pts[1], g1pts[2], g1pts[3], g1pts[5]};
-    A2 b2[5] = {g2pts[0], g2pts[1], g2pts[2], g2pts[3], g2pts[5]};
+    HIPCHK(c, hipMemcpy(g1pts.data(), c->crs_g1.p, g1pts.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g2pts.data(), c->crs_g2.p, g2pts.size(), hipMemcpyDeviceToHost));
+    // window tables (internal form) for bases {u0.0,u0.1,u1.0,u1.1,W.1}
+    std::vector<uint8_t> b1(5 * Z::G1), b2(5 * Z::G2);
+    memcpy(&b1[0], &g1pts[0], 4 * Z::G1);
+    memcpy(&b1[4 * Z::G1], &g1pts[5 * Z::G1], Z::G1);
+    memcpy(&b2[0], &g2pts[0], 4 * Z::G2);
+    memcpy(&b2[4 * Z::G2], &g2pts[5 * Z::G2], Z::G2);
     void *db1, *db2;
-    RC(scratch(c, "crs.b1", sizeof b1, &db1));
-    RC(scratch(c, "crs.b2", sizeof b2, &db2));
-    HIPCHK(c, hipMemcpy(db1, b1, sizeof b1, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(db2, b2, sizeof b2, hipMemcpyHostToDevice));
+    RC(scratch(c, "crs.b1", b1.size(), &db1));
+    RC(scratch(c, "crs.b2", b2.size(), &db2));
+    HIPCHK(c, hipMemcpy(db1, b1.data(), b1.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db2, b2.data(), b2.size(), hipMemcpyHostToDevice));
     size_t ne = (size_t)5 * 32 * 256;
     RC(ensure(c, c->tab_g1, ne * sizeof(A1)));
     RC(ensure(c, c->tab_g2, ne * sizeof(A2)));
-    RC(launch(c, "k_build_tables.g1", k_build_tables<C, F1>, ne, 64, 5, (const A1*)db1, (A1*)c->tab_g1.p));
-    RC(launch(c, "k_build_tables.g2", k_build_tables<C, F2>, ne, 64, 5, (const A2*)db2, (A2*)c->tab_g2.p));
+    RC(launch(c, "k_build_tables.g1", k_build_tables<C, F1>, ne, 64, 5, (const uint8_t*)db1, (A1*)c->tab_g1.p));
+    RC(launch(c, "k_build_tables.g2", k_build_tables<C, F2>, ne, 64, 5, (const uint8_t*)db2, (A2*)c->tab_g2.p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_crs = true;
     return GS_OK;
@@ -345,9 +348,9 @@ template <class C> struct Impl {
       memset(&arrs, 0, sizeof arrs);
       if (xg) {
         arrs.base[0] = (const uint8_t*)X;
-        arrs.stride[0] = (uint32_t)(m * sizeof(A1));
+        arrs.stride[0] = (uint32_t)(m * Z::G1);
         arrs.base[1] = (const uint8_t*)A;
-        arrs.stride[1] = (uint32_t)(n * sizeof(A1));
+        arrs.stride[1] = (uint32_t)(n * Z::G1);
       }
       OutTab outs;
       memset(&outs, 0, sizeof outs);
@@ -365,9 +368,9 @@ template <class C> struct Impl {
       memset(&arrs, 0, sizeof arrs);
       if (yg) {
         arrs.base[0] = (const uint8_t*)Y;
-        arrs.stride[0] = (uint32_t)(n * sizeof(A2));
+        arrs.stride[0] = (uint32_t)(n * Z::G2);
         arrs.base[1] = (const uint8_t*)B;
-        arrs.stride[1] = (uint32_t)(m * sizeof(A2));
+        arrs.stride[1] = (uint32_t)(m * Z::G2);
       }
       OutTab outs;
       memset(&outs, 0, sizeof outs);
@@ -385,6 +388,7 @@ template <class C> struct Impl {
   static int commit(gs_ctx* c, size_t count, bool group, const void* vars, const void* rand, void* out,
                     const Aff<F>* tab, const char* tag) {
     int kc = group ? 2 : 1;
+    const size_t bsz = sizeof(Aff<F>) == sizeof(A1) ? Z::G1 : Z::G2;  // boundary bytes of one point
     PoolMap pm;
     memset(&pm, 0, sizeof pm);
     pm.RC = 0;
@@ -402,12 +406,12 @@ template <class C> struct Impl {
     memset(&arrs, 0, sizeof arrs);
     if (group) {
       arrs.base[0] = (const uint8_t*)vars;
-      arrs.stride[0] = (uint32_t)sizeof(Aff<F>);
+      arrs.stride[0] = (uint32_t)bsz;
     }
     OutTab outs;
     memset(&outs, 0, sizeof outs);
     outs.base[0] = (uint8_t*)out;
-    outs.stride[0] = (uint32_t)(2 * sizeof(Aff<F>));
+    outs.stride[0] = (uint32_t)(2 * bsz);
     return run_side<C, F>(c, tag, count, sp, arrs, (const S*)pool, pm.total, tab, outs);
   }
 
@@ -524,11 +528,11 @@ template <class C> struct Impl {
       arrs.stride[0] = (uint32_t)(m * Z::COM1);
       if (xg) {
         arrs.base[1] = (const uint8_t*)A;
-        arrs.stride[1] = (uint32_t)(n * sizeof(A1));
+        arrs.stride[1] = (uint32_t)(n * Z::G1);
       }
       if (ty == GS_MSMEG1) {
         arrs.base[2] = (const uint8_t*)target;
-        arrs.stride[2] = (uint32_t)sizeof(A1);
+        arrs.stride[2] = (uint32_t)Z::G1;
       }
       OutTab outs;
       memset(&outs, 0, sizeof outs);
@@ -556,13 +560,13 @@ template <class C> struct Impl {
     qarr.base[0] = (const uint8_t*)ycoms;
     qarr.stride[0] = (uint32_t)(n * Z::COM2);
     qarr.base[1] = (const uint8_t*)B;
-    qarr.stride[1] = (uint32_t)(m * sizeof(A2));
+    qarr.stride[1] = (uint32_t)(m * Z::G2);
     qarr.base[2] = (const uint8_t*)c->crs_g2.p;
     qarr.stride[2] = 0;
     qarr.base[3] = (const uint8_t*)pi;
     qarr.stride[3] = (uint32_t)(kx * Z::COM2);
     qarr.base[4] = (const uint8_t*)target;
-    qarr.stride[4] = (uint32_t)sizeof(A2);
+    qarr.stride[4] = (uint32_t)Z::G2;
     RC(launch(c, "k_miller", k_miller<C>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
     *mpart_out = mpart;
     return GS_OK;
@@ -578,13 +582,14 @@ template <class C> struct Impl {
     void* cellok;
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
     RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cb[0], vp.cb[1], vp.cb[2], vp.cb[3], vp.cb[4],
-              (const GT*)mpart, ty == GS_PPE ? (const GT*)target : nullptr, (uint8_t*)cellok));
+              (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
     RC(launch(c, "k_and4", k_and4, N, 256, N, (const uint8_t*)cellok, ok));
     return GS_OK;
   }
 
-  // product of n GT elements at `buf` (clobbers buf/tmp), result copied to dst[0]
-  static int gt_product(gs_ctx* c, size_t n, GT* buf, GT* tmp, GT* dst) {
+  // product of n internal-form GT elements at `buf` (clobbers buf/tmp); result exported in
+  // boundary form to dst (one GT)
+  static int gt_product(gs_ctx* c, size_t n, GT* buf, GT* tmp, uint8_t* dst) {
     const int K = 8;
     GT *in = buf, *out = tmp;
     while (n > 1) {
@@ -595,7 +600,7 @@ template <class C> struct Impl {
       out = t;
       n = no;
     }
-    HIPCHK(c, hipMemcpyAsync(dst, in, sizeof(GT), hipMemcpyDeviceToDevice, c->stream));
+    RC(launch(c, "k_gt_export", k_gt_export<C>, 1, 64, (size_t)1, (const GT*)in, dst));
     return GS_OK;
   }
 
@@ -609,37 +614,43 @@ template <class C> struct Impl {
     int ntask = (int)vp.mt.size();
     void *pf, *pt, *tmp;
     RC(scratch(c, "rlc.f", N * 4 * sizeof(GT), &pf));
-    RC(scratch(c, "rlc.t", N * sizeof(GT), &pt));
+    RC(scratch(c, "rlc.t", (N + 1) * sizeof(GT), &pt));
     RC(scratch(c, "rlc.tmp", (N / 2 + 8) * sizeof(GT), &tmp));
     RC(launch(c, "k_rlc_pow", k_rlc_pow<C>, N * 4, 64, N, ntask, vp.cb[0], vp.cb[1], vp.cb[2], vp.cb[3], vp.cb[4],
-              (const GT*)mpart, ty == GS_PPE ? (const GT*)target : nullptr, rho, (GT*)pf, (GT*)pt));
-    GT* a = (GT*)acc;
+              (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, rho, (GT*)pf, (GT*)pt));
+    uint8_t* a = (uint8_t*)acc;
     RC(gt_product(c, N * 4, (GT*)pf, (GT*)tmp, a));
-    if (ty == GS_PPE)
-      RC(gt_product(c, N, (GT*)pt, (GT*)tmp, a + 1));
-    else
-      RC(launch(c, "k_gt_set_one", k_gt_set_one<C>, 1, 64, a + 1));
+    if (ty == GS_PPE) {
+      RC(gt_product(c, N, (GT*)pt, (GT*)tmp, a + Z::GT));
+    } else {
+      RC(launch(c, "k_gt_set_one", k_gt_set_one<C>, 1, 64, (GT*)pt));
+      RC(launch(c, "k_gt_export", k_gt_export<C>, 1, 64, (size_t)1, (const GT*)pt, a + Z::GT));
+    }
     return GS_OK;
   }
 
-  // accs: count pairs (host).  ok = FE(prod accs[i][0]) == prod accs[i][1]
+  // accs: count boundary-form pairs (host).  ok = FE(prod accs[i][0]) == prod accs[i][1]
   static int gt_finalize(gs_ctx* c, size_t count, const void* accs_host, uint8_t* ok_host) {
-    void *d, *t, *two, *dok;
+    void *raw, *d, *t, *two, *dok, *twob;
+    RC(scratch(c, "fin.raw", 2 * count * Z::GT, &raw));
     RC(scratch(c, "fin.in", 2 * count * sizeof(GT), &d));
     RC(scratch(c, "fin.tmp", (count + 8) * sizeof(GT), &t));
     RC(scratch(c, "fin.two", 2 * sizeof(GT), &two));
+    RC(scratch(c, "fin.twob", 2 * Z::GT, &twob));
     RC(scratch(c, "fin.ok", 16, &dok));
     // de-interleave on the host: [f0 f1 ...][t0 t1 ...]
-    std::vector<uint8_t> h(2 * count * sizeof(GT));
+    std::vector<uint8_t> h(2 * count * Z::GT);
     const uint8_t* src = (const uint8_t*)accs_host;
     for (size_t i = 0; i < count; i++) {
-      memcpy(&h[i * sizeof(GT)], src + (2 * i) * sizeof(GT), sizeof(GT));
-      memcpy(&h[(count + i) * sizeof(GT)], src + (2 * i + 1) * sizeof(GT), sizeof(GT));
+      memcpy(&h[i * Z::GT], src + (2 * i) * Z::GT, Z::GT);
+      memcpy(&h[(count + i) * Z::GT], src + (2 * i + 1) * Z::GT, Z::GT);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice));
-    RC(gt_product(c, count, (GT*)d, (GT*)t, (GT*)two));
-    RC(gt_product(c, count, (GT*)d + count, (GT*)t, (GT*)two + 1));
+    HIPCHK(c, hipMemcpy(raw, h.data(), h.size(), hipMemcpyHostToDevice));
+    RC(launch(c, "k_gt_import", k_gt_import<C>, 2 * count, 64, 2 * count, (const uint8_t*)raw, (GT*)d));
+    RC(gt_product(c, count, (GT*)d, (GT*)t, (uint8_t*)twob));
+    RC(gt_product(c, count, (GT*)d + count, (GT*)t, (uint8_t*)twob + Z::GT));
+    RC(launch(c, "k_gt_import", k_gt_import<C>, 2, 64, (size_t)2, (const uint8_t*)twob, (GT*)two));
     RC(launch(c, "k_fe_eq", k_fe_eq<C>, 1, 64, (const GT*)two, (uint8_t*)dok));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(ok_host, dok, 1, hipMemcpyDeviceToHost));
@@ -653,7 +664,7 @@ template <class C> struct Impl {
 #define DISPATCH(ctx, EXPR)                                   \
   ((ctx)->curve == GS_CURVE_BLS12_381 ? Impl<Bls12_381>::EXPR : Impl<Bn254>::EXPR)
 
-static size_t sz_fq(int curve) { return curve == 0 ? sizeof(Fq<Bls12_381>) : sizeof(Fq<Bn254>); }
+static size_t sz_fq(int curve) { return curve == 0 ? 4 * Bls12_381::N : 4 * Bn254::N; }
 static const size_t SZ_FR = 32;
 
 struct HostStage {  // host<->device staging for the un-suffixed entry points
@@ -704,7 +715,7 @@ static int check_ctx(gs_ctx* c, bool need_crs) {
 template <class C, class F>
 static int left_mul_impl(gs_ctx* c, int rows, int k, const void* lhs, const void* col, void* out) {
   typedef Fr<C> S;
-  size_t com = 2 * sizeof(Aff<F>);
+  size_t com = 2 * (sizeof(Aff<F>) == sizeof(Aff<Fq<C>>) ? Sz<C>::G1 : Sz<C>::G2);
   HostStage st(c);
   void *dl, *dc, *dout;
   RC(st.in(lhs, (size_t)rows * k * sizeof(S), &dl));
@@ -935,19 +946,19 @@ int gs_g1_mul_batch_dev(gs_ctx* c, size_t n, const void* p, int bc, const void* 
   RC(check_ctx(c, false));
   if (n == 0) return GS_OK;
   if (c->curve == 0)
-    return launch(c, "k_smul_batch.g1", k_smul_batch<Bls12_381, Fq<Bls12_381>>, n, 64, n,
-                  (const Aff<Fq<Bls12_381>>*)p, bc, (const Fr<Bls12_381>*)k, (Aff<Fq<Bls12_381>>*)out);
-  return launch(c, "k_smul_batch.g1", k_smul_batch<Bn254, Fq<Bn254>>, n, 64, n, (const Aff<Fq<Bn254>>*)p, bc,
-                (const Fr<Bn254>*)k, (Aff<Fq<Bn254>>*)out);
+    return launch(c, "k_smul_batch.g1", k_smul_batch<Bls12_381, Fq<Bls12_381>>, n, 64, n, (const uint8_t*)p, bc,
+                  (const Fr<Bls12_381>*)k, (uint8_t*)out);
+  return launch(c, "k_smul_batch.g1", k_smul_batch<Bn254, Fq<Bn254>>, n, 64, n, (const uint8_t*)p, bc,
+                (const Fr<Bn254>*)k, (uint8_t*)out);
 }
 int gs_g2_mul_batch_dev(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
   RC(check_ctx(c, false));
   if (n == 0) return GS_OK;
   if (c->curve == 0)
-    return launch(c, "k_smul_batch.g2", k_smul_batch<Bls12_381, Fp2<Bls12_381>>, n, 64, n,
-                  (const Aff<Fp2<Bls12_381>>*)p, bc, (const Fr<Bls12_381>*)k, (Aff<Fp2<Bls12_381>>*)out);
-  return launch(c, "k_smul_batch.g2", k_smul_batch<Bn254, Fp2<Bn254>>, n, 64, n, (const Aff<Fp2<Bn254>>*)p, bc,
-                (const Fr<Bn254>*)k, (Aff<Fp2<Bn254>>*)out);
+    return launch(c, "k_smul_batch.g2", k_smul_batch<Bls12_381, Fp2<Bls12_381>>, n, 64, n, (const uint8_t*)p, bc,
+                  (const Fr<Bls12_381>*)k, (uint8_t*)out);
+  return launch(c, "k_smul_batch.g2", k_smul_batch<Bn254, Fp2<Bn254>>, n, 64, n, (const uint8_t*)p, bc,
+                (const Fr<Bn254>*)k, (uint8_t*)out);
 }
 int gs_g1_mul_batch(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
   RC(check_ctx(c, false));
@@ -977,10 +988,10 @@ int gs_multi_pairing_batch_dev(gs_ctx* c, size_t n, int k, const void* p, const 
   if (n == 0) return GS_OK;
   if (k < 0) return GS_ERR_ARG;
   if (c->curve == 0)
-    return launch(c, "k_multi_pairing", k_multi_pairing<Bls12_381>, n, 64, n, k, (const Aff<Fq<Bls12_381>>*)p,
-                  (const Aff<Fp2<Bls12_381>>*)q, (Fp12<Bls12_381>*)out);
-  return launch(c, "k_multi_pairing", k_multi_pairing<Bn254>, n, 64, n, k, (const Aff<Fq<Bn254>>*)p,
-                (const Aff<Fp2<Bn254>>*)q, (Fp12<Bn254>*)out);
+    return launch(c, "k_multi_pairing", k_multi_pairing<Bls12_381>, n, 64, n, k, (const uint8_t*)p,
+                  (const uint8_t*)q, (uint8_t*)out);
+  return launch(c, "k_multi_pairing", k_multi_pairing<Bn254>, n, 64, n, k, (const uint8_t*)p, (const uint8_t*)q,
+                (uint8_t*)out);
 }
 int gs_multi_pairing_batch(gs_ctx* c, size_t n, int k, const void* p, const void* q, void* out) {
   RC(check_ctx(c, false));
@@ -998,10 +1009,9 @@ int gs_gt_pow_batch_dev(gs_ctx* c, size_t n, const void* base, const void* k, vo
   RC(check_ctx(c, false));
   if (n == 0) return GS_OK;
   if (c->curve == 0)
-    return launch(c, "k_gt_pow", k_gt_pow<Bls12_381>, n, 64, n, (const Fp12<Bls12_381>*)base,
-                  (const Fr<Bls12_381>*)k, (Fp12<Bls12_381>*)out);
-  return launch(c, "k_gt_pow", k_gt_pow<Bn254>, n, 64, n, (const Fp12<Bn254>*)base, (const Fr<Bn254>*)k,
-                (Fp12<Bn254>*)out);
+    return launch(c, "k_gt_pow", k_gt_pow<Bls12_381>, n, 64, n, (const uint8_t*)base, (const Fr<Bls12_381>*)k,
+                  (uint8_t*)out);
+  return launch(c, "k_gt_pow", k_gt_pow<Bn254>, n, 64, n, (const uint8_t*)base, (const Fr<Bn254>*)k, (uint8_t*)out);
 }
 
 // ComT::pairing_sum: four multi-pairings over the component selections (a,b)

@@ -18,7 +18,8 @@ template <class F> struct Jac {
   F x, y, z;
 };
 
-template <class F> GS_HD bool aff_is_inf(const Aff<F>& p) { return is_zero(p.x) && is_zero(p.y); }
+// identity flags are EXACT zeros (never lazily reduced representatives): see gs_fq28.cuh
+template <class F> GS_HD bool aff_is_inf(const Aff<F>& p) { return is_zero_limbs(p.x) && is_zero_limbs(p.y); }
 template <class F> GS_HD void jac_set_inf(Jac<F>& r) {
   r.x = one_of<F>();
   r.y = one_of<F>();
@@ -38,18 +39,21 @@ template <class F> GS_HD void aff_neg(Aff<F>& r, const Aff<F>& p) {
   r.y = neg(p.y);
 }
 
+// All coordinates are stored normalised (N); the comments give the limb-growth A of
+// the lazy intermediates (gs_tower.cuh header).
+
 // dbl-2009-l: 2M + 5S
 template <class F> GS_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
   F a = sqr(p.x), b = sqr(p.y), c = sqr(b);
-  F d = dbl(sub(sub(sqr(add(p.x, b)), a), c));
-  F e = add(dbl(a), a);
+  F d = norm(dbl(sub(sub(sqr_l2(add(p.x, b)), a), c)));  // 2 * 3 = 6 -> N
+  F e = norm(add(dbl(a), a));                            // 3 -> N
   F f = sqr(e);
-  F z3 = dbl(mul(p.y, p.z));
-  F x3 = sub(f, dbl(d));
-  F c8 = dbl(dbl(dbl(c)));
-  r.y = sub(mul(e, sub(d, x3)), c8);
+  F z3 = norm(dbl(mul(p.y, p.z)));
+  F x3 = norm(sub(f, dbl(d)));                           // 3 -> N
+  F c8 = dbl(norm(dbl(dbl(c))));                         // 8c with A = 2
+  r.y = norm(sub(mul(e, norm(sub(d, x3))), c8));
   r.x = x3;
-  r.z = z3;  // Z = 0 stays 0
+  r.z = z3;  // Z = 0 (exact) stays exactly 0
 }
 
 // madd-2007-bl with full edge-case handling: r = p + q (q affine)
@@ -58,7 +62,7 @@ template <class F> GS_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, cons
     r = p;
     return;
   }
-  if (is_zero(p.z)) {
+  if (is_zero_limbs(p.z)) {
     r.x = q.x;
     r.y = q.y;
     r.z = one_of<F>();
@@ -67,7 +71,7 @@ template <class F> GS_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, cons
   F z1z1 = sqr(p.z);
   F u2 = mul(q.x, z1z1);
   F s2 = mul(mul(q.y, p.z), z1z1);
-  F h = sub(u2, p.x);
+  F h = norm(sub(u2, p.x));
   F rr = sub(s2, p.y);
   if (is_zero(h)) {
     if (is_zero(rr)) {
@@ -77,14 +81,14 @@ template <class F> GS_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, cons
     }
     return;
   }
-  rr = dbl(rr);
+  rr = norm(dbl(rr));  // 4 -> N
   F hh = sqr(h);
-  F i = dbl(dbl(hh));
+  F i = norm(dbl(dbl(hh)));
   F j = mul(h, i);
   F v = mul(p.x, i);
-  F x3 = sub(sub(sqr(rr), j), dbl(v));
-  F y3 = sub(mul(rr, sub(v, x3)), dbl(mul(p.y, j)));
-  F z3 = sub(sub(sqr(add(p.z, h)), z1z1), hh);
+  F x3 = norm(sub(sub(sqr(rr), j), dbl(v)));  // 4 -> N
+  F y3 = norm(sub(mul(rr, norm(sub(v, x3))), dbl(mul(p.y, j))));
+  F z3 = norm(sub(sub(sqr_l2(add(p.z, h)), z1z1), hh));
   r.x = x3;
   r.y = y3;
   r.z = z3;
@@ -92,18 +96,18 @@ template <class F> GS_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, cons
 
 // add-2007-bl with full edge-case handling: r = p + q
 template <class F> GS_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
-  if (is_zero(q.z)) {
+  if (is_zero_limbs(q.z)) {
     r = p;
     return;
   }
-  if (is_zero(p.z)) {
+  if (is_zero_limbs(p.z)) {
     r = q;
     return;
   }
   F z1z1 = sqr(p.z), z2z2 = sqr(q.z);
   F u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
   F s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
-  F h = sub(u2, u1);
+  F h = norm(sub(u2, u1));
   F rr = sub(s2, s1);
   if (is_zero(h)) {
     if (is_zero(rr)) {
@@ -113,13 +117,13 @@ template <class F> GS_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const
     }
     return;
   }
-  rr = dbl(rr);
-  F i = sqr(dbl(h));
+  rr = norm(dbl(rr));
+  F i = sqr(norm(dbl(h)));
   F j = mul(h, i);
   F v = mul(u1, i);
-  F x3 = sub(sub(sqr(rr), j), dbl(v));
-  F y3 = sub(mul(rr, sub(v, x3)), dbl(mul(s1, j)));
-  F z3 = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+  F x3 = norm(sub(sub(sqr(rr), j), dbl(v)));
+  F y3 = norm(sub(mul(rr, norm(sub(v, x3))), dbl(mul(s1, j))));
+  F z3 = mul(norm(sub(sub(sqr_l2(add(p.z, q.z)), z1z1), z2z2)), h);
   r.x = x3;
   r.y = y3;
   r.z = z3;
@@ -133,7 +137,7 @@ template <class F> GS_HD void jac_neg(Jac<F>& r, const Jac<F>& p) {
 
 // normalise with a known z^-1
 template <class F> GS_HD void jac_to_aff_zinv(Aff<F>& r, const Jac<F>& p, const F& zinv) {
-  if (is_zero(p.z)) {
+  if (is_zero_limbs(p.z)) {
     r.x = zero_of<F>();
     r.y = zero_of<F>();
     return;

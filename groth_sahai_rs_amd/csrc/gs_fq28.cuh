@@ -1,0 +1,351 @@
+// Base field Fq in an UNSATURATED radix-2^28 signed-limb representation, built
+// for what gfx950's VALU is good at (measured, profiles/r1/ubench_valu.txt):
+//   * v_mad_i64_i32 / v_mad_u64_u32 (32x32 + 64-bit accumulate): ~4 cycles
+//   * carry-flag arithmetic (v_add_co / v_addc_co): ALSO ~4 cycles per instruction
+//   * plain v_add_u32 / v_and / shifts: ~2 cycles
+// A saturated 32-bit-limb Montgomery product needs a carry-flag instruction per
+// multiply-accumulate and every modular add/sub is a 36-instruction carry chain.
+// With 28-bit limbs up to 14+14 products fit a signed 64-bit accumulator, so a
+// Montgomery product is L*L*2 bare mads (+ ~6 ops per column) and field
+// add/sub/neg are L independent full-rate adds with NO reduction at all.
+//
+// Representation: element a is held as the integer  V = a * 2^(28 L) mod p, lazily
+// reduced: V may be any representative with |V| < 2^(28L-6), limbs are int32 with
+// V = sum v[i] 2^(28 i).  "Normalised" means v[0..L-2] in [0, 2^28 + small) and the
+// top limb signed.  mul() returns normalised limbs and a value in (-p/2, 3p/2).
+// Contract for mul(a, b): 14 * max|a_i| * max|b_j| + 14 * 2^56 < 2^63, i.e. the
+// limb-growth factors satisfy A*B <= 8 (a sum of two normalised values has A = 2);
+// callers call norm() where a longer sum feeds a product.  With GS_FQ28_CHECK
+// (CPU twin only) every mul asserts the contract.
+//
+// Boundary form (arkworks, include/gs_amd.h) is canonical saturated Montgomery
+// with radix 2^(32N); fq_from_boundary / fq_to_boundary convert with one
+// multiplication each, only at kernel inputs/outputs.
+#pragma once
+#include "gs_field.cuh"
+#if defined(GS_FQ28_CHECK)
+#include <stdio.h>
+#include <stdlib.h>
+#endif
+
+namespace gs {
+
+constexpr int32_t M28 = 0x0FFFFFFF;
+
+#if defined(GS_FQ28_CHECK)
+typedef int64_t limb_t;  // CPU-twin debug build: wide limbs so that int32 overflow is detectable
+#define GS_CHK_LIMBS(r)                                                                        \
+  for (int i_ = 0; i_ < C::L; i_++)                                                            \
+    if ((r).v[i_] >= ((int64_t)1 << 31) || (r).v[i_] < -((int64_t)1 << 31)) {                 \
+      fprintf(stderr, "Fq28 limb overflow (|limb| >= 2^31) at %s:%d\n", __FILE__, __LINE__);   \
+      abort();                                                                                 \
+    }
+#else
+typedef int32_t limb_t;
+#define GS_CHK_LIMBS(r)
+#endif
+
+template <class C> struct Fq28 {
+  limb_t v[C::L];
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM)
+#include "gs_mul28_asm.h"
+#endif
+
+// ---- lazy linear operations (no carries, no reduction) -------------------------
+template <class C> GS_HD Fq28<C> add(const Fq28<C>& a, const Fq28<C>& b) {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = a.v[i] + b.v[i];
+  GS_CHK_LIMBS(r)
+  return r;
+}
+template <class C> GS_HD Fq28<C> sub(const Fq28<C>& a, const Fq28<C>& b) {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = a.v[i] - b.v[i];
+  GS_CHK_LIMBS(r)
+  return r;
+}
+template <class C> GS_HD Fq28<C> neg(const Fq28<C>& a) {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = -a.v[i];
+  return r;
+}
+template <class C> GS_HD Fq28<C> dbl(const Fq28<C>& a) {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = a.v[i] * 2;
+  GS_CHK_LIMBS(r)
+  return r;
+}
+template <class C> GS_HD Fq28<C> mul_small(const Fq28<C>& a, int k) {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = a.v[i] * k;
+  GS_CHK_LIMBS(r)
+  return r;
+}
+template <class C> GS_HD Fq28<C> select(bool c, const Fq28<C>& a, const Fq28<C>& b) {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+template <class C> GS_HD Fq28<C> fq_zero() {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = 0;
+  return r;
+}
+template <class C> GS_HD Fq28<C> fq_one() {
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = C::ONE28[i];
+  return r;
+}
+// exact all-limbs-zero test: used for identity flags (identities are always
+// stored as exact zeros and exact zero is absorbing under mul/dbl)
+template <class C> GS_HD bool is_zero_limbs(const Fq28<C>& a) {
+  limb_t o = 0;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) o |= a.v[i];
+  return o == 0;
+}
+
+// one parallel carry round: limbs 0..L-2 back to [0, 2^28 + small), top signed
+template <class C> GS_HD Fq28<C> norm(const Fq28<C>& a) {
+  Fq28<C> r;
+  r.v[0] = a.v[0] & M28;
+#pragma unroll
+  for (int i = 1; i < C::L - 1; i++) r.v[i] = (a.v[i] & M28) + (a.v[i - 1] >> 28);
+  r.v[C::L - 1] = a.v[C::L - 1] + (a.v[C::L - 2] >> 28);
+  return r;
+}
+// sequential carry propagation: unique limb vector for the integer V
+template <class C> GS_HD Fq28<C> norm_full(const Fq28<C>& a) {
+  Fq28<C> r;
+  limb_t c = 0;
+#pragma unroll
+  for (int i = 0; i < C::L - 1; i++) {
+    limb_t t = a.v[i] + c;
+    r.v[i] = t & M28;
+    c = t >> 28;
+  }
+  r.v[C::L - 1] = a.v[C::L - 1] + c;
+  return r;
+}
+
+// value reduction: subtract round(V/p) * p (quotient estimated in f32 from the two top
+// limbs).  Needed only where a value is fed back LINEARLY (cyclotomic squaring:
+// z <- 3t - 2z doubles |V| per step); everywhere else multiplication contracts values.
+// Input: weakly normalised limbs, |V| < 2^20 p.  Output: unique limbs, |V| <= ~p.
+template <class C> GS_HD Fq28<C> vreduce(const Fq28<C>& a) {
+  constexpr int L = C::L;
+  float v = (float)a.v[L - 1] * 268435456.0f + (float)a.v[L - 2];
+  int32_t k = (int32_t)__builtin_rintf(v * C::INV_PTOP2);
+  Fq28<C> r;
+  int64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < L - 1; i++) {
+    acc += (int64_t)a.v[i] - (int64_t)k * C::P28[i];
+    r.v[i] = (limb_t)(((uint32_t)acc) & (uint32_t)M28);
+    acc >>= 28;
+  }
+  r.v[L - 1] = (limb_t)((int64_t)a.v[L - 1] - (int64_t)k * C::P28[L - 1] + acc);
+  return r;
+}
+
+// ---- Montgomery product ----------------------------------------------------------
+template <class C, class T> GS_HD void mul28_generic(T* r, const T* a, const T* b) {
+  constexpr int L = C::L;
+  uint32_t m[L];
+  int64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (j < 0 || j >= L) continue;
+      acc += (int64_t)a[i] * b[j];
+      if (j >= 1 && i < k) acc += (int64_t)(int32_t)m[i] * C::P28[j];
+    }
+    if (k < L) {
+      m[k] = ((((uint32_t)acc) & (uint32_t)M28) * C::P28_INV) & (uint32_t)M28;
+      acc += (int64_t)(int32_t)m[k] * C::P28[0];
+      acc >>= 28;
+    } else {
+      r[k - L] = (T)(((uint32_t)acc) & (uint32_t)M28);
+      acc >>= 28;
+    }
+  }
+  r[L - 1] = (T)acc;
+}
+
+#if defined(GS_FQ28_CHECK)
+template <class C> inline void fq28_check(const Fq28<C>& a, const Fq28<C>& b) {
+  int64_t ma = 0, mb = 0;
+  for (int i = 0; i < C::L; i++) {
+    int64_t x = a.v[i] < 0 ? -(int64_t)a.v[i] : a.v[i], y = b.v[i] < 0 ? -(int64_t)b.v[i] : b.v[i];
+    if (x > ma) ma = x;
+    if (y > mb) mb = y;
+  }
+  // sum of L products + L reduction terms must stay below 2^63
+  __int128 worst = (__int128)C::L * ma * mb + (__int128)C::L * ((__int128)1 << 56);
+  int64_t ta = a.v[C::L - 1] < 0 ? -(int64_t)a.v[C::L - 1] : a.v[C::L - 1];
+  int64_t tb = b.v[C::L - 1] < 0 ? -(int64_t)b.v[C::L - 1] : b.v[C::L - 1];
+  // value sanity: |V| < 2^(28L - 2); mul contracts values (|ab|/R + p), lazy chains stay far below this,
+  // only linear feedback (cyclotomic squaring) needs vreduce()
+  bool val_ok = ta < (1 << 26) && tb < (1 << 26);
+  if (worst >= ((__int128)1 << 63) || !val_ok) {
+    fprintf(stderr, "Fq28 mul contract violated: max|a_i|=%lld max|b_j|=%lld top %lld %lld\n", (long long)ma,
+            (long long)mb, (long long)ta, (long long)tb);
+    abort();
+  }
+}
+#endif
+
+// register-passing wrapper: the out-of-line body takes/returns ext-vectors so that
+// operands stay in VGPRs across the call (same trick as gs_field.cuh)
+typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+template <class C> GS_HD_NOINLINE i32x16 mul28_vec(i32x16 a, i32x16 b) {
+  int32_t av[C::L], bv[C::L], rv[C::L];
+#pragma unroll
+  for (int i = 0; i < C::L; i++) {
+    av[i] = a[i];
+    bv[i] = b[i];
+  }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM)
+  if constexpr (C::L == 14)
+    mul28_asm_14<C>(rv, av, bv);
+  else
+    mul28_asm_10<C>(rv, av, bv);
+#else
+  mul28_generic<C, int32_t>(rv, av, bv);
+#endif
+  i32x16 r = 0;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r[i] = rv[i];
+  return r;
+}
+
+template <class C> GS_HD Fq28<C> mul(const Fq28<C>& a, const Fq28<C>& b) {
+#if defined(GS_FQ28_CHECK)
+  fq28_check(a, b);
+  Fq28<C> rr;
+  mul28_generic<C, limb_t>(rr.v, a.v, b.v);
+  return rr;
+#endif
+  i32x16 av = 0, bv = 0;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) {
+    av[i] = a.v[i];
+    bv[i] = b.v[i];
+  }
+  i32x16 rv = mul28_vec<C>(av, bv);
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = rv[i];
+  return r;
+}
+template <class C> GS_HD Fq28<C> sqr(const Fq28<C>& a) { return mul(a, a); }
+
+// ---- tests modulo p --------------------------------------------------------------
+// robust a == 0 (mod p) for any lazily reduced a within the mul contract: one
+// multiplication by 1 brings the value into (-p/2, 3p/2) with unique limbs, where
+// the only multiples of p are 0 and p.
+template <class C> GS_HD bool is_zero(const Fq28<C>& a) {
+  Fq28<C> t = norm_full(mul(norm(a), fq_one<C>()));
+  limb_t z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) {
+    z |= t.v[i];
+    e |= t.v[i] ^ C::P28[i];
+  }
+  return z == 0 || e == 0;
+}
+template <class C> GS_HD bool eq(const Fq28<C>& a, const Fq28<C>& b) { return is_zero(sub(a, b)); }
+
+// a^(p-2); inv(0) = 0.  4-bit fixed window over the constant exponent.
+template <class C> GS_HD_NOINLINE void inv28_raw(limb_t* out, const limb_t* in) {
+  Fq28<C> a;
+  for (int i = 0; i < C::L; i++) a.v[i] = in[i];
+  Fq28<C> tab[16];
+  tab[0] = fq_one<C>();
+  tab[1] = a;
+  for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
+  // exponent p - 2 from the saturated constant C::P (32-bit limbs)
+  Fq28<C> r = fq_one<C>();
+  bool started = false;
+  for (int w = C::N * 8 - 1; w >= 0; w--) {
+    int limb = w >> 3, sh = (w & 7) * 4;
+    uint32_t e = C::P[limb];
+    if (limb == 0) e -= 2;
+    uint32_t dgt = (e >> sh) & 15u;
+    if (started) {
+      r = sqr(r);
+      r = sqr(r);
+      r = sqr(r);
+      r = sqr(r);
+    }
+    if (dgt) {
+      r = started ? mul(r, tab[dgt]) : tab[dgt];
+      started = true;
+    }
+  }
+  for (int i = 0; i < C::L; i++) out[i] = r.v[i];
+}
+template <class C> GS_HD Fq28<C> inv(const Fq28<C>& a) {
+  Fq28<C> n = norm(a), r;
+  inv28_raw<C>(r.v, n.v);
+  return r;
+}
+
+// ---- boundary conversion ---------------------------------------------------------
+// canonical saturated limbs (N x u32, value < p) -> internal
+template <class C> GS_HD Fq28<C> fq_from_boundary(const uint32_t* w) {
+  Fq28<C> t;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) {
+    int bit = 28 * i;
+    int lo = bit >> 5, sh = bit & 31;
+    uint64_t x = 0;
+    if (lo < C::N) x = w[lo];
+    if (lo + 1 < C::N) x |= (uint64_t)w[lo + 1] << 32;
+    t.v[i] = (limb_t)((uint32_t)(x >> sh) & (uint32_t)M28);
+  }
+  Fq28<C> k;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) k.v[i] = C::K_IN28[i];
+  return mul(t, k);
+}
+// internal -> canonical saturated limbs
+template <class C> GS_HD void fq_to_boundary(uint32_t* w, const Fq28<C>& a) {
+  Fq28<C> k;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) k.v[i] = C::K_OUT28[i];
+  Fq28<C> t = norm_full(mul(norm(a), k));  // value in (-p/2, 3p/2)
+  // bring into [0, p)
+  Fq28<C> p;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) p.v[i] = C::P28[i];
+  Fq28<C> plus = norm_full(add(t, p)), minus = norm_full(sub(t, p));
+  bool negv = t.v[C::L - 1] < 0;
+  bool big = minus.v[C::L - 1] >= 0;  // t - p >= 0
+  Fq28<C> c = negv ? plus : (big ? minus : t);
+  // repack 28 -> 32
+#pragma unroll
+  for (int j = 0; j < C::N; j++) {
+    int bit = 32 * j;
+    int lo = bit / 28, sh = bit % 28;
+    uint64_t x = (uint64_t)(uint32_t)c.v[lo] >> sh;
+    int got = 28 - sh;
+    if (lo + 1 < C::L) x |= (uint64_t)(uint32_t)c.v[lo + 1] << got;
+    if (lo + 2 < C::L && got + 28 < 32) x |= (uint64_t)(uint32_t)c.v[lo + 2] << (got + 28);
+    w[j] = (uint32_t)x;
+  }
+}
+
+}  // namespace gs

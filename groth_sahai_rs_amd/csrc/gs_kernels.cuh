@@ -57,43 +57,87 @@ struct PoolMap {  // offsets (in scalars) into the per-equation pool
 
 template <class T> __device__ __forceinline__ T ld(const uint8_t* p) { return *reinterpret_cast<const T*>(p); }
 
+// ---- boundary <-> internal I/O --------------------------------------------------
+// API arrays hold arkworks' saturated Montgomery limbs (BFq); everything the
+// kernels keep between launches (window tables, Jacobian partials, Miller partials)
+// stays in the internal radix-2^28 form.
+template <class C> constexpr size_t aff_bytes(const Aff<Fq<C>>*) { return 2 * sizeof(BFq<C>); }
+template <class C> constexpr size_t aff_bytes(const Aff<Fp2<C>>*) { return 4 * sizeof(BFq<C>); }
+template <class C> GS_HD void aff_load(Aff<Fq<C>>& r, const uint8_t* p) {
+  const BFq<C>* b = reinterpret_cast<const BFq<C>*>(p);
+  BFq<C> x = b[0], y = b[1];
+  r.x = fq_from_boundary<C>(x.w);
+  r.y = fq_from_boundary<C>(y.w);
+}
+template <class C> GS_HD void aff_load(Aff<Fp2<C>>& r, const uint8_t* p) {
+  const BFq<C>* b = reinterpret_cast<const BFq<C>*>(p);
+  BFq<C> t[4] = {b[0], b[1], b[2], b[3]};
+  r.x = fp2_from_boundary<C>(t);
+  r.y = fp2_from_boundary<C>(t + 2);
+}
+template <class C> GS_HD void aff_store(uint8_t* p, const Aff<Fq<C>>& a) {
+  BFq<C>* b = reinterpret_cast<BFq<C>*>(p);
+  BFq<C> x, y;
+  fq_to_boundary<C>(x.w, a.x);
+  fq_to_boundary<C>(y.w, a.y);
+  b[0] = x;
+  b[1] = y;
+}
+template <class C> GS_HD void aff_store(uint8_t* p, const Aff<Fp2<C>>& a) {
+  BFq<C>* b = reinterpret_cast<BFq<C>*>(p);
+  BFq<C> t[4];
+  fp2_to_boundary<C>(t, a.x);
+  fp2_to_boundary<C>(t + 2, a.y);
+  b[0] = t[0];
+  b[1] = t[1];
+  b[2] = t[2];
+  b[3] = t[3];
+}
+#define AFFB(C, F) (aff_bytes<C>((const Aff<F>*)nullptr))
+
 // --------------------------------------------------------------------------
 // generic helpers
 // --------------------------------------------------------------------------
 template <class C, class F>
-__global__ void __launch_bounds__(64, GS_WPE) k_smul_batch(size_t n, const Aff<F>* p, int broadcast, const Fr<C>* k,
-                                                   Aff<F>* out) {
+__global__ void __launch_bounds__(64, GS_WPE) k_smul_batch(size_t n, const uint8_t* p, int broadcast, const Fr<C>* k,
+                                                   uint8_t* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Aff<F> P = p[broadcast ? 0 : i];
+  Aff<F> P;
+  aff_load<C>(P, p + (broadcast ? 0 : i) * AFFB(C, F));
   Jac<F> J;
   jac_smul(J, P, from_mont(k[i]));
   Aff<F> R;
   jac_to_aff(R, J);
-  out[i] = R;
+  aff_store<C>(out + i * AFFB(C, F), R);
 }
 
 // pts[5] <- pts[3] + pts[5]  (W.1 = u1.1 + generator), single lane
-template <class C, class F> __global__ void k_crs_derive(Aff<F>* pts) {
+template <class C, class F> __global__ void k_crs_derive(uint8_t* pts) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Aff<F> a, b;
+  aff_load<C>(a, pts + 3 * AFFB(C, F));
+  aff_load<C>(b, pts + 5 * AFFB(C, F));
   Jac<F> j;
-  jac_from_aff(j, pts[3]);
-  jac_madd(j, j, pts[5]);
+  jac_from_aff(j, a);
+  jac_madd(j, j, b);
   Aff<F> r;
   jac_to_aff(r, j);
-  pts[5] = r;
+  aff_store<C>(pts + 5 * AFFB(C, F), r);
 }
 
 // window tables: tab[(b*32 + w)*256 + d] = d * 2^(8w) * base[b]   (d = 0 -> identity)
 template <class C, class F>
-__global__ void __launch_bounds__(64, GS_WPE) k_build_tables(int nb, const Aff<F>* bases, Aff<F>* tab) {
+__global__ void __launch_bounds__(64, GS_WPE) k_build_tables(int nb, const uint8_t* bases, Aff<F>* tab) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nb * 32 * 256) return;
   int d = (int)(i & 255), w = (int)((i >> 8) & 31), b = (int)(i >> 13);
   Fr<C> k = fzero<FrM<C>>();
   k.v[w >> 2] = (uint32_t)d << ((w & 3) * 8);
+  Aff<F> B;
+  aff_load<C>(B, bases + b * AFFB(C, F));
   Jac<F> J;
-  jac_smul(J, bases[b], k);
+  jac_smul(J, B, k);
   Aff<F> R;
   jac_to_aff(R, J);
   tab[i] = R;
@@ -181,7 +225,8 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, con
   size_t e = g / ntask;
   VarTask t = tasks[g % ntask];
   Fr<C> k = pool[e * pool_n + t.s_idx];
-  Aff<F> P = ld<Aff<F>>(arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * sizeof(Aff<F>));
+  Aff<F> P;
+  aff_load<C>(P, arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
   Jac<F> J;
   jac_smul(J, P, k);
   part[e * nslots + t.slot] = J;
@@ -211,7 +256,8 @@ __global__ void __launch_bounds__(64, GS_WPE) k_fix(size_t total, int ntask, con
     }
   }
   if (t.a_arr != 0xFF) {
-    Aff<F> q = ld<Aff<F>>(arrs.base[t.a_arr] + e * arrs.stride[t.a_arr] + (size_t)t.a_idx * sizeof(Aff<F>));
+    Aff<F> q;
+    aff_load<C>(q, arrs.base[t.a_arr] + e * arrs.stride[t.a_arr] + (size_t)t.a_idx * AFFB(C, F));
     if (t.a_neg) q.y = neg(q.y);
     jac_madd(acc, acc, q);
   }
@@ -230,16 +276,16 @@ __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, con
   for (int i = t.b0 + 1; i < t.e0; i++) jac_add(s0, s0, P[i]);
   for (int i = t.b1 + 1; i < t.e1; i++) jac_add(s1, s1, P[i]);
   // one inversion for both components
-  bool i0 = is_zero(s0.z), i1 = is_zero(s1.z);
+  bool i0 = is_zero_limbs(s0.z), i1 = is_zero_limbs(s1.z);
   F z0 = i0 ? one_of<F>() : s0.z, z1 = i1 ? one_of<F>() : s1.z;
   F zi = inv(mul(z0, z1));
   F zi0 = mul(zi, z1), zi1 = mul(zi, z0);
   Aff<F> a0, a1;
   jac_to_aff_zinv(a0, s0, zi0);
   jac_to_aff_zinv(a1, s1, zi1);
-  Aff<F>* o = reinterpret_cast<Aff<F>*>(outs.base[t.out_arr] + e * outs.stride[t.out_arr]) + 2 * (size_t)t.out_idx;
-  o[0] = a0;
-  o[1] = a1;
+  uint8_t* o = outs.base[t.out_arr] + e * outs.stride[t.out_arr] + 2 * (size_t)t.out_idx * AFFB(C, F);
+  aff_store<C>(o, a0);
+  aff_store<C>(o + AFFB(C, F), a1);
 }
 
 // --------------------------------------------------------------------------
@@ -258,8 +304,8 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, 
   bool live[MILLER_CH];
   for (int k = 0; k < t.np; k++) {
     PairRef r = t.pr[k];
-    ps[k] = ld<Aff<Fq<C>>>(parr.base[r.p_arr] + e * parr.stride[r.p_arr] + (size_t)r.p_idx * sizeof(Aff<Fq<C>>));
-    qs[k] = ld<Aff<Fp2<C>>>(qarr.base[r.q_arr] + e * qarr.stride[r.q_arr] + (size_t)r.q_idx * sizeof(Aff<Fp2<C>>));
+    aff_load<C>(ps[k], parr.base[r.p_arr] + e * parr.stride[r.p_arr] + (size_t)r.p_idx * AFFB(C, Fq<C>));
+    aff_load<C>(qs[k], qarr.base[r.q_arr] + e * qarr.stride[r.q_arr] + (size_t)r.q_idx * AFFB(C, Fp2<C>));
     if (r.neg) ps[k].y = neg(ps[k].y);
   }
   Fp12<C> f;
@@ -271,7 +317,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, 
 // check (FE, compare with 1 or the PPE target) -> cellok[e*4+c].
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4,
-                                              const Fp12<C>* mpart, const Fp12<C>* target, uint8_t* cellok) {
+                                              const Fp12<C>* mpart, const uint8_t* target, uint8_t* cellok) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * 4) return;
   size_t e = g >> 2;
@@ -284,7 +330,8 @@ __global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, int c
   final_exp(r, f);
   bool ok;
   if (c == 3 && target) {
-    Fp12<C> t = target[e];
+    Fp12<C> t;
+    f12_from_boundary<C>(t, reinterpret_cast<const BFq<C>*>(target) + 12 * e);
     ok = f12_eq(r, t);
   } else {
     ok = f12_is_one(r);
@@ -301,8 +348,8 @@ __global__ void k_and4(size_t N, const uint8_t* cellok, uint8_t* ok) {
 
 // E::multi_pairing per row: k pairs -> Miller product -> final exponentiation
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE) k_multi_pairing(size_t n, int k, const Aff<Fq<C>>* P, const Aff<Fp2<C>>* Q,
-                                                      Fp12<C>* out) {
+__global__ void __launch_bounds__(64, GS_WPE) k_multi_pairing(size_t n, int k, const uint8_t* P, const uint8_t* Q,
+                                                      uint8_t* out) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   Aff<Fq<C>> ps[MILLER_CH];
@@ -314,36 +361,45 @@ __global__ void __launch_bounds__(64, GS_WPE) k_multi_pairing(size_t n, int k, c
   for (int b = 0; b < k; b += MILLER_CH) {
     int np = k - b < MILLER_CH ? k - b : MILLER_CH;
     for (int i = 0; i < np; i++) {
-      ps[i] = P[g * k + b + i];
-      qs[i] = Q[g * k + b + i];
+      aff_load<C>(ps[i], P + (g * k + b + i) * AFFB(C, Fq<C>));
+      aff_load<C>(qs[i], Q + (g * k + b + i) * AFFB(C, Fp2<C>));
     }
     multi_miller(f, ps, qs, np, ts, live);
     f12_mul(acc, acc, f);
   }
   final_exp(f, acc);
-  out[g] = f;
+  f12_to_boundary<C>(reinterpret_cast<BFq<C>*>(out) + 12 * g, f);
 }
 
 // out[i] = base^(k[i]) for base in GT (cyclotomic squarings are valid)
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE) k_gt_pow(size_t n, const Fp12<C>* base, const Fr<C>* k, Fp12<C>* out) {
+__global__ void __launch_bounds__(64, GS_WPE) k_gt_pow(size_t n, const uint8_t* base, const Fr<C>* k, uint8_t* out) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   Fr<C> s = from_mont(k[g]);
-  Fp12<C> b = base[0], acc;
+  Fp12<C> b, acc;
+  f12_from_boundary<C>(b, reinterpret_cast<const BFq<C>*>(base));
   f12_one(acc);
   bool started = false;
+  int since = 0;
   for (int i = FrM<C>::BITS - 1; i >= 0; i--) {
-    if (started) f12_cyclo_sqr(acc, acc);
+    if (started) {
+      f12_cyclo_sqr(acc, acc);
+      since++;
+    }
     if (get_bit(s, i)) {
       if (started)
         f12_mul(acc, acc, b);
       else
         acc = b;
       started = true;
+      since = 0;
+    } else if (since == 3) {
+      f12_vreduce(acc);
+      since = 0;
     }
   }
-  out[g] = acc;
+  f12_to_boundary<C>(reinterpret_cast<BFq<C>*>(out) + 12 * g, acc);
 }
 
 // ---- batched (random-linear-combination) verifier -------------------------------
@@ -369,7 +425,7 @@ template <class C> GS_HD_NOINLINE void f12_pow_u64(Fp12<C>& r, const Fp12<C>& b,
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE)
     k_rlc_pow(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4, const Fp12<C>* mpart,
-              const Fp12<C>* target, const uint64_t* rho, Fp12<C>* out_f, Fp12<C>* out_t) {
+              const uint8_t* target, const uint64_t* rho, Fp12<C>* out_f, Fp12<C>* out_t) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * 4) return;
   size_t e = g >> 2;
@@ -382,7 +438,8 @@ __global__ void __launch_bounds__(64, GS_WPE)
   f12_pow_u64(h, f, rho[g]);
   out_f[g] = h;
   if (c == 3 && target) {
-    Fp12<C> t = target[e];
+    Fp12<C> t;
+    f12_from_boundary<C>(t, reinterpret_cast<const BFq<C>*>(target) + 12 * e);
     f12_pow_u64(h, t, rho[g]);
     out_t[e] = h;
   }
@@ -397,6 +454,19 @@ __global__ void __launch_bounds__(64, GS_WPE) k_gt_prod(size_t n_in, const Fp12<
   Fp12<C> acc = in[lo];
   for (size_t i = lo + 1; i < hi; i++) f12_mul(acc, acc, in[i]);
   out[g] = acc;
+}
+// internal <-> boundary copies of GT arrays (accumulators cross the API in boundary form)
+template <class C> __global__ void __launch_bounds__(64, GS_WPE) k_gt_export(size_t n, const Fp12<C>* in, uint8_t* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  f12_to_boundary<C>(reinterpret_cast<BFq<C>*>(out) + 12 * g, in[g]);
+}
+template <class C> __global__ void __launch_bounds__(64, GS_WPE) k_gt_import(size_t n, const uint8_t* in, Fp12<C>* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Fp12<C> t;
+  f12_from_boundary<C>(t, reinterpret_cast<const BFq<C>*>(in) + 12 * g);
+  out[g] = t;
 }
 // acc[0] = Miller-side accumulator, acc[1] = target-side accumulator: ok = (FE(acc[0]) == acc[1])
 template <class C> __global__ void k_fe_eq(const Fp12<C>* acc, uint8_t* ok) {

@@ -31,47 +31,50 @@ template <class C> struct Line {
 template <class C> GS_HD Fp2<C> twist_b3() {
   Fp2<C> r;
 #pragma unroll
-  for (int i = 0; i < C::N; i++) {
-    r.c0.v[i] = C::B2X3[0][i];
-    r.c1.v[i] = C::B2X3[1][i];
+  for (int i = 0; i < C::L; i++) {
+    r.c0.v[i] = C::B2X3_28[0][i];
+    r.c1.v[i] = C::B2X3_28[1][i];
   }
   return r;
 }
 
-// T <- 2T, returns the tangent line coefficients.
+// T <- 2T, returns the tangent line coefficients (all N).  The new point is the
+// classical (X3, Y3, Z3) scaled by 4 -- the same projective point, no halvings:
+//   X3 = 2XY (B - F), Y3 = (B + F)^2 - 12 E^2, Z3 = 4 B H
+// with B = Y^2, E = 3 b' Z^2, F = 3E, H = 2YZ.
 template <class C> GS_HD_NOINLINE void miller_dbl(Proj2<C>& t, Line<C>& l) {
-  Fp2<C> a = half(mul(t.x, t.y));
+  Fp2<C> xy = mul(t.x, t.y);
   Fp2<C> b = sqr(t.y);
   Fp2<C> c = sqr(t.z);
-  Fp2<C> e = mul(twist_b3<C>(), c);  // 3 b' Z^2
-  Fp2<C> f = add(dbl(e), e);         // 9 b' Z^2
-  Fp2<C> g = half(add(b, f));
-  Fp2<C> h = sub(sqr(add(t.y, t.z)), add(b, c));  // 2 Y Z
+  Fp2<C> e = mul(twist_b3<C>(), c);                           // 3 b' Z^2
+  Fp2<C> f = norm(add(dbl(e), e));                            // 9 b' Z^2
+  Fp2<C> h = norm(sub(sub(sqr_l2(add(t.y, t.z)), b), c));     // 2 Y Z
   Fp2<C> j = sqr(t.x);
   Fp2<C> e2 = sqr(e);
-  l.l0 = sub(b, e);                 // Y^2 - 3 b' Z^2
-  l.lx = neg(add(dbl(j), j));       // -3 X^2
-  l.ly = h;                         // 2 Y Z
-  t.x = mul(a, sub(b, f));
-  t.y = sub(sqr(g), add(dbl(e2), e2));
-  t.z = mul(b, h);
+  l.l0 = norm(sub(b, e));                                     // Y^2 - 3 b' Z^2
+  l.lx = norm(neg(add(dbl(j), j)));                           // -3 X^2
+  l.ly = h;                                                   // 2 Y Z
+  Fp2<C> e2x4 = norm(dbl(dbl(e2)));
+  t.x = mul(norm(dbl(xy)), norm(sub(b, f)));
+  t.y = norm(sub(sqr(norm(add(b, f))), add(dbl(e2x4), e2x4)));
+  t.z = mul(b, norm(dbl(dbl(h))));
 }
 
-// T <- T + Q (Q affine on the twist), returns the chord line coefficients.
+// T <- T + Q (Q affine on the twist), returns the chord line coefficients (all N).
 template <class C> GS_HD_NOINLINE void miller_add(Proj2<C>& t, Line<C>& l, const Aff<Fp2<C>>& q) {
-  Fp2<C> theta = sub(t.y, mul(q.y, t.z));
-  Fp2<C> lambda = sub(t.x, mul(q.x, t.z));
+  Fp2<C> theta = norm(sub(t.y, mul(q.y, t.z)));
+  Fp2<C> lambda = norm(sub(t.x, mul(q.x, t.z)));
   Fp2<C> c = sqr(theta);
   Fp2<C> d = sqr(lambda);
   Fp2<C> e = mul(lambda, d);
   Fp2<C> f = mul(t.z, c);
   Fp2<C> g = mul(t.x, d);
-  Fp2<C> h = sub(add(e, f), dbl(g));
-  l.l0 = sub(mul(theta, q.x), mul(lambda, q.y));
+  Fp2<C> h = norm(sub(add(e, f), dbl(g)));
+  l.l0 = norm(sub(mul(theta, q.x), mul(lambda, q.y)));
   l.lx = neg(theta);
   l.ly = lambda;
   t.x = mul(lambda, h);
-  t.y = sub(mul(theta, sub(g, h)), mul(e, t.y));
+  t.y = norm(sub(mul(theta, norm(sub(g, h))), mul(e, t.y)));
   t.z = mul(t.z, e);
 }
 
@@ -144,9 +147,18 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f
   Fp12<C> acc = f;
   int top = 63;
   while (!((C::X_ABS >> top) & 1)) top--;
+  int since = 0;
   for (int i = top - 1; i >= 0; i--) {
     f12_cyclo_sqr(acc, acc);
-    if ((C::X_ABS >> i) & 1) f12_mul(acc, acc, f);
+    // Granger-Scott squaring feeds 2*z back linearly: values double per step; a
+    // full multiplication contracts them again, otherwise reduce every 3rd step
+    if ((C::X_ABS >> i) & 1) {
+      f12_mul(acc, acc, f);
+      since = 0;
+    } else if (++since == 3) {
+      f12_vreduce(acc);
+      since = 0;
+    }
   }
   if (C::X_NEG) f12_conj(acc, acc);
   r = acc;

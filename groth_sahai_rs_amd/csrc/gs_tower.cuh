@@ -3,19 +3,26 @@
 //
 // Replaces arkworks' Fp2/Fp6/Fp12 models (ark-ff ^0.5, external to the
 // reference; reached from ComT ops src/data_structures.rs:399-466 and from
-// E::pairing / E::multi_pairing :484-502).  Element order in memory matches
-// arkworks: Fp12{c0,c1: Fp6}, Fp6{c0,c1,c2: Fp2}, Fp2{c0,c1: Fp}.
+// E::pairing / E::multi_pairing :484-502).  Coefficient order matches arkworks:
+// Fp12{c0,c1: Fp6}, Fp6{c0,c1,c2: Fp2}, Fp2{c0,c1: Fp}.
+//
+// Base field = Fq28 (gs_fq28.cuh): lazily reduced radix-2^28 limbs.  Limb-growth
+// discipline ("A" = max |limb| / 2^28):
+//   * every multiplication returns A ~ 1 ("N");  add/sub/neg/dbl/mul_xi are lazy
+//     (A adds up) and must stay below A = 7.9 (int32);
+//   * Fq mul needs A*B <= 8;  Fp2 mul/sqr need N inputs (Karatsuba sums double A),
+//     mul_l2/sqr_l2 accept A <= 2 inputs and normalise their internal sums;
+//   * Fp6 / Fp12 functions take N inputs and return N outputs.
+// The CPU twin built with -DGS_FQ28_CHECK asserts all of this at run time.
 //
 // Fp2 values travel in registers (by value); Fp6/Fp12 operations are
-// out-of-line and work on memory operands (an Fp12 is 144 dwords -- it cannot
-// live in VGPRs next to anything else), which also keeps the hot loops within
-// the instruction cache.
+// out-of-line and work on memory operands (an Fp12 is 168 dwords).
 #pragma once
-#include "gs_field.cuh"
+#include "gs_fq28.cuh"
 
 namespace gs {
 
-template <class C> using Fq = Fe<FqM<C>>;
+template <class C> using Fq = Fq28<C>;
 template <class C> using Fr = Fe<FrM<C>>;
 
 // ------------------------------------------------------------------ Fp2 ----
@@ -28,61 +35,60 @@ template <class C> GS_HD Fp2<C> sub(const Fp2<C>& a, const Fp2<C>& b) { return {
 template <class C> GS_HD Fp2<C> neg(const Fp2<C>& a) { return {neg(a.c0), neg(a.c1)}; }
 template <class C> GS_HD Fp2<C> dbl(const Fp2<C>& a) { return {dbl(a.c0), dbl(a.c1)}; }
 template <class C> GS_HD Fp2<C> conj(const Fp2<C>& a) { return {a.c0, neg(a.c1)}; }
+template <class C> GS_HD Fp2<C> norm(const Fp2<C>& a) { return {norm(a.c0), norm(a.c1)}; }
+template <class C> GS_HD Fp2<C> mul_small(const Fp2<C>& a, int k) { return {mul_small(a.c0, k), mul_small(a.c1, k)}; }
 template <class C> GS_HD bool is_zero(const Fp2<C>& a) { return is_zero(a.c0) && is_zero(a.c1); }
-template <class C> GS_HD bool eq(const Fp2<C>& a, const Fp2<C>& b) { return eq(a.c0, b.c0) && eq(a.c1, b.c1); }
+template <class C> GS_HD bool is_zero_limbs(const Fp2<C>& a) { return is_zero_limbs(a.c0) && is_zero_limbs(a.c1); }
+template <class C> GS_HD bool eq(const Fp2<C>& a, const Fp2<C>& b) { return is_zero(sub(a, b)); }
 template <class C> GS_HD Fp2<C> select(bool c, const Fp2<C>& a, const Fp2<C>& b) {
   return {select(c, a.c0, b.c0), select(c, a.c1, b.c1)};
 }
+// Karatsuba; inputs N, output N
 template <class C> GS_HD Fp2<C> mul(const Fp2<C>& a, const Fp2<C>& b) {
   Fq<C> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1);
   Fq<C> s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
-  return {sub(v0, v1), sub(sub(s, v0), v1)};
+  return {sub(v0, v1), norm(sub(sub(s, v0), v1))};
+}
+// inputs with A <= 2 (e.g. one sum of two N values)
+template <class C> GS_HD Fp2<C> mul_l2(const Fp2<C>& a, const Fp2<C>& b) {
+  Fq<C> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1);
+  Fq<C> s = mul(norm(add(a.c0, a.c1)), norm(add(b.c0, b.c1)));
+  return {sub(v0, v1), norm(sub(sub(s, v0), v1))};
 }
 template <class C> GS_HD Fp2<C> sqr(const Fp2<C>& a) {
   Fq<C> t = mul(a.c0, a.c1);
-  return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(t)};
+  return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), norm(dbl(t))};
+}
+template <class C> GS_HD Fp2<C> sqr_l2(const Fp2<C>& a) {
+  Fq<C> t = mul(a.c0, a.c1);
+  return {mul(norm(add(a.c0, a.c1)), norm(sub(a.c0, a.c1))), norm(dbl(t))};
 }
 template <class C> GS_HD Fp2<C> mul_fp(const Fp2<C>& a, const Fq<C>& k) { return {mul(a.c0, k), mul(a.c1, k)}; }
+// lazy: A_out = (XI_A + 1) * A_in
 template <class C> GS_HD Fp2<C> mul_xi(const Fp2<C>& a) {
   if (C::XI_A == 1) return {sub(a.c0, a.c1), add(a.c0, a.c1)};
-  // (A + u)(a0 + a1 u) = (A a0 - a1) + (A a1 + a0) u
-  return {sub(mul_small(a.c0, C::XI_A), a.c1), add(mul_small(a.c1, C::XI_A), a.c0)};
+  // (9 + u)(a0 + a1 u) = (9 a0 - a1) + (9 a1 + a0) u ; 8x is normalised on the way (A_in <= 1.9)
+  Fq<C> e0 = norm(mul_small(a.c0, 4)), e1 = norm(mul_small(a.c1, 4));
+  e0 = norm(dbl(e0));
+  e1 = norm(dbl(e1));
+  return {sub(add(e0, a.c0), a.c1), add(add(e1, a.c1), a.c0)};
 }
 template <class C> GS_HD Fp2<C> inv(const Fp2<C>& a) {
   Fq<C> n = inv(add(sqr(a.c0), sqr(a.c1)));
   return {mul(a.c0, n), neg(mul(a.c1, n))};
 }
-template <class C> GS_HD Fp2<C> mul_small(const Fp2<C>& a, int k) { return {mul_small(a.c0, k), mul_small(a.c1, k)}; }
+
+// generic helpers for code templated on F = Fq or Fp2
+template <class C> GS_HD Fq<C> mul_l2(const Fq<C>& a, const Fq<C>& b) { return mul(a, b); }  // 2*2 <= 8
+template <class C> GS_HD Fq<C> sqr_l2(const Fq<C>& a) { return mul(a, a); }
 
 template <class F> GS_HD F zero_of();
 template <class F> GS_HD F one_of();
-#define GS_ZERO_ONE(CURVE)                                                              \
-  template <> GS_HD Fq<CURVE> zero_of<Fq<CURVE>>() { return fzero<FqM<CURVE>>(); }      \
-  template <> GS_HD Fq<CURVE> one_of<Fq<CURVE>>() { return fone<FqM<CURVE>>(); }        \
-  template <> GS_HD Fp2<CURVE> zero_of<Fp2<CURVE>>() {                                  \
-    return {fzero<FqM<CURVE>>(), fzero<FqM<CURVE>>()};                                  \
-  }                                                                                     \
-  template <> GS_HD Fp2<CURVE> one_of<Fp2<CURVE>>() { return {fone<FqM<CURVE>>(), fzero<FqM<CURVE>>()}; }
-
-// halve: (a + (a odd ? p : 0)) >> 1
-template <class M> GS_HD Fe<M> half(const Fe<M>& a) {
-  constexpr int N = M::N;
-  uint32_t mask = 0u - (a.v[0] & 1u);
-  uint32_t t[N];
-  uint32_t c = 0;
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    uint64_t x = (uint64_t)a.v[j] + (M::mod(j) & mask) + c;
-    t[j] = (uint32_t)x;
-    c = (uint32_t)(x >> 32);
-  }
-  Fe<M> r;
-#pragma unroll
-  for (int j = 0; j < N - 1; j++) r.v[j] = (t[j] >> 1) | (t[j + 1] << 31);
-  r.v[N - 1] = (t[N - 1] >> 1) | (c << 31);
-  return r;
-}
-template <class C> GS_HD Fp2<C> half(const Fp2<C>& a) { return {half(a.c0), half(a.c1)}; }
+#define GS_ZERO_ONE(CURVE)                                                                     \
+  template <> GS_HD Fq<CURVE> zero_of<Fq<CURVE>>() { return fq_zero<CURVE>(); }                \
+  template <> GS_HD Fq<CURVE> one_of<Fq<CURVE>>() { return fq_one<CURVE>(); }                  \
+  template <> GS_HD Fp2<CURVE> zero_of<Fp2<CURVE>>() { return {fq_zero<CURVE>(), fq_zero<CURVE>()}; } \
+  template <> GS_HD Fp2<CURVE> one_of<Fp2<CURVE>>() { return {fq_one<CURVE>(), fq_zero<CURVE>()}; }
 
 // ------------------------------------------------------------------ Fp6 ----
 template <class C> struct Fp6 {
@@ -104,36 +110,47 @@ template <class C> GS_HD void f6_neg(Fp6<C>& r, const Fp6<C>& a) {
   r.c1 = neg(a.c1);
   r.c2 = neg(a.c2);
 }
-// r = a * v   (v^3 = xi)
+template <class C> GS_HD void f6_norm(Fp6<C>& r, const Fp6<C>& a) {
+  r.c0 = norm(a.c0);
+  r.c1 = norm(a.c1);
+  r.c2 = norm(a.c2);
+}
+// r = norm(a + b), r = norm(a - b)
+template <class C> GS_HD void f6_addn(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
+  r.c0 = norm(add(a.c0, b.c0));
+  r.c1 = norm(add(a.c1, b.c1));
+  r.c2 = norm(add(a.c2, b.c2));
+}
+// r = a * v   (v^3 = xi); N in -> N out
 template <class C> GS_HD void f6_mul_v(Fp6<C>& r, const Fp6<C>& a) {
-  Fp2<C> t = mul_xi(a.c2);
+  Fp2<C> t = norm(mul_xi(a.c2));
   r.c2 = a.c1;
   r.c1 = a.c0;
   r.c0 = t;
 }
-// Karatsuba, 6 Fp2 multiplications.  r may alias a or b.
+// Karatsuba, 6 Fp2 multiplications.  r may alias a or b.  N in -> N out.
 template <class C> GS_HD_NOINLINE void f6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
   Fp2<C> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1), v2 = mul(a.c2, b.c2);
-  Fp2<C> t0 = sub(sub(mul(add(a.c1, a.c2), add(b.c1, b.c2)), v1), v2);
-  Fp2<C> t1 = sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), v0), v1);
-  Fp2<C> t2 = sub(sub(mul(add(a.c0, a.c2), add(b.c0, b.c2)), v0), v2);
-  r.c0 = add(v0, mul_xi(t0));
-  r.c1 = add(t1, mul_xi(v2));
-  r.c2 = add(t2, v1);
+  Fp2<C> t0 = sub(sub(mul_l2(add(a.c1, a.c2), add(b.c1, b.c2)), v1), v2);  // A = 3
+  Fp2<C> t1 = sub(sub(mul_l2(add(a.c0, a.c1), add(b.c0, b.c1)), v0), v1);
+  Fp2<C> t2 = sub(sub(mul_l2(add(a.c0, a.c2), add(b.c0, b.c2)), v0), v2);
+  r.c0 = norm(add(v0, mul_xi(norm(t0))));
+  r.c1 = norm(add(t1, mul_xi(v2)));
+  r.c2 = norm(add(t2, v1));
 }
 // a * (b0 + b1 v): 5 Fp2 multiplications
 template <class C> GS_HD_NOINLINE void f6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {
   Fp2<C> v0 = mul(a.c0, b0), v1 = mul(a.c1, b1);
-  Fp2<C> t0 = sub(mul(add(a.c1, a.c2), b1), v1);                    // a2*b1
-  Fp2<C> t1 = sub(sub(mul(add(a.c0, a.c1), add(b0, b1)), v0), v1);  // a0 b1 + a1 b0
-  Fp2<C> t2 = sub(mul(add(a.c0, a.c2), b0), v0);                    // a2*b0
-  r.c0 = add(v0, mul_xi(t0));
-  r.c1 = t1;
-  r.c2 = add(t2, v1);
+  Fp2<C> t0 = sub(mul_l2(add(a.c1, a.c2), b1), v1);                        // a2*b1
+  Fp2<C> t1 = sub(sub(mul_l2(add(a.c0, a.c1), add(b0, b1)), v0), v1);      // a0 b1 + a1 b0
+  Fp2<C> t2 = sub(mul_l2(add(a.c0, a.c2), b0), v0);                        // a2*b0
+  r.c0 = norm(add(v0, mul_xi(norm(t0))));
+  r.c1 = norm(t1);
+  r.c2 = norm(add(t2, v1));
 }
 // a * (b1 v): 3 Fp2 multiplications
 template <class C> GS_HD void f6_mul_by_1(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b1) {
-  Fp2<C> t0 = mul_xi(mul(a.c2, b1));
+  Fp2<C> t0 = norm(mul_xi(mul(a.c2, b1)));
   Fp2<C> t1 = mul(a.c0, b1);
   Fp2<C> t2 = mul(a.c1, b1);
   r.c0 = t0;
@@ -146,10 +163,11 @@ template <class C> GS_HD void f6_mul_fp2(Fp6<C>& r, const Fp6<C>& a, const Fp2<C
   r.c2 = mul(a.c2, k);
 }
 template <class C> GS_HD_NOINLINE void f6_inv(Fp6<C>& r, const Fp6<C>& a) {
-  Fp2<C> t0 = sub(sqr(a.c0), mul_xi(mul(a.c1, a.c2)));
-  Fp2<C> t1 = sub(mul_xi(sqr(a.c2)), mul(a.c0, a.c1));
-  Fp2<C> t2 = sub(sqr(a.c1), mul(a.c0, a.c2));
-  Fp2<C> n = add(mul(a.c0, t0), mul_xi(add(mul(a.c2, t1), mul(a.c1, t2))));
+  Fp2<C> t0 = norm(sub(sqr(a.c0), mul_xi(mul(a.c1, a.c2))));
+  Fp2<C> t1 = norm(sub(norm(mul_xi(sqr(a.c2))), mul(a.c0, a.c1)));
+  Fp2<C> t2 = norm(sub(sqr(a.c1), mul(a.c0, a.c2)));
+  Fp2<C> s = norm(add(mul(a.c2, t1), mul(a.c1, t2)));
+  Fp2<C> n = norm(add(mul(a.c0, t0), mul_xi(s)));
   Fp2<C> ni = inv(n);
   r.c0 = mul(t0, ni);
   r.c1 = mul(t1, ni);
@@ -170,38 +188,32 @@ template <class C> GS_HD void f12_one(Fp12<C>& r) {
   r.c1.c1 = z;
   r.c1.c2 = z;
 }
-template <class C> GS_HD bool f12_eq(const Fp12<C>& a, const Fp12<C>& b) {
-  return eq(a.c0.c0, b.c0.c0) && eq(a.c0.c1, b.c0.c1) && eq(a.c0.c2, b.c0.c2) && eq(a.c1.c0, b.c1.c0) &&
-         eq(a.c1.c1, b.c1.c1) && eq(a.c1.c2, b.c1.c2);
-}
-template <class C> GS_HD bool f12_is_one(const Fp12<C>& a) {
-  return eq(a.c0.c0, one_of<Fp2<C>>()) && is_zero(a.c0.c1) && is_zero(a.c0.c2) && is_zero(a.c1.c0) &&
-         is_zero(a.c1.c1) && is_zero(a.c1.c2);
-}
 template <class C> GS_HD_NOINLINE void f12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {
   Fp6<C> t0, t1, sa, sb, m;
   f6_mul(t0, a.c0, b.c0);
   f6_mul(t1, a.c1, b.c1);
-  f6_add(sa, a.c0, a.c1);
-  f6_add(sb, b.c0, b.c1);
+  f6_addn(sa, a.c0, a.c1);
+  f6_addn(sb, b.c0, b.c1);
   f6_mul(m, sa, sb);
   f6_sub(m, m, t0);
-  f6_sub(r.c1, m, t1);
+  f6_sub(m, m, t1);
+  f6_norm(r.c1, m);
   f6_mul_v(t1, t1);
-  f6_add(r.c0, t0, t1);
+  f6_addn(r.c0, t0, t1);
 }
 // complex squaring: 2 Fp6 multiplications
 template <class C> GS_HD_NOINLINE void f12_sqr(Fp12<C>& r, const Fp12<C>& a) {
   Fp6<C> v0, s0, s1, t;
   f6_mul(v0, a.c0, a.c1);
-  f6_add(s0, a.c0, a.c1);
+  f6_addn(s0, a.c0, a.c1);
   f6_mul_v(t, a.c1);
-  f6_add(s1, a.c0, t);
+  f6_addn(s1, a.c0, t);
   f6_mul(s0, s0, s1);  // (a0+a1)(a0+v a1) = a0^2 + v a1^2 + (1+v) a0 a1
-  f6_sub(s0, s0, v0);
   f6_mul_v(t, v0);
-  f6_sub(r.c0, s0, t);
-  f6_add(r.c1, v0, v0);
+  f6_sub(s0, s0, v0);
+  f6_sub(s0, s0, t);
+  f6_norm(r.c0, s0);
+  f6_addn(r.c1, v0, v0);
 }
 template <class C> GS_HD void f12_conj(Fp12<C>& r, const Fp12<C>& a) {
   r.c0 = a.c0;
@@ -213,6 +225,7 @@ template <class C> GS_HD_NOINLINE void f12_inv(Fp12<C>& r, const Fp12<C>& a) {
   f6_mul(t1, a.c1, a.c1);
   f6_mul_v(t1, t1);
   f6_sub(t0, t0, t1);
+  f6_norm(t0, t0);
   f6_inv(t1, t0);
   f6_mul(r.c0, a.c0, t1);
   f6_mul(t0, a.c1, t1);
@@ -222,9 +235,9 @@ template <class C> GS_HD_NOINLINE void f12_inv(Fp12<C>& r, const Fp12<C>& a) {
 template <class C> GS_HD Fp2<C> frob_coeff(int j, int k) {
   Fp2<C> r;
 #pragma unroll
-  for (int i = 0; i < C::N; i++) {
-    r.c0.v[i] = (j == 1) ? C::FROB1[k][0][i] : (j == 2) ? C::FROB2[k][0][i] : C::FROB3[k][0][i];
-    r.c1.v[i] = (j == 1) ? C::FROB1[k][1][i] : (j == 2) ? C::FROB2[k][1][i] : C::FROB3[k][1][i];
+  for (int i = 0; i < C::L; i++) {
+    r.c0.v[i] = (j == 1) ? C::FROB1_28[k][0][i] : (j == 2) ? C::FROB2_28[k][0][i] : C::FROB3_28[k][0][i];
+    r.c1.v[i] = (j == 1) ? C::FROB1_28[k][1][i] : (j == 2) ? C::FROB2_28[k][1][i] : C::FROB3_28[k][1][i];
   }
   return r;
 }
@@ -247,18 +260,19 @@ template <class C> GS_HD_NOINLINE void f12_frob(Fp12<C>& r, const Fp12<C>& a, in
   r.c1.c2 = mul(x, frob_coeff<C>(j, 5));
 }
 
-// f *= (l0 + l1 v) + (l4 v) w      -- line shape of an M-type twist (BLS12-381)
+// f *= (l0 + l1 v) + (l4 v) w      -- line shape of an M-type twist (BLS12-381); l* are N
 template <class C>
 GS_HD_NOINLINE void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const Fp2<C>& l4) {
   Fp6<C> aa, bb, s, t;
   f6_mul_by_01(aa, f.c0, l0, l1);
   f6_mul_by_1(bb, f.c1, l4);
-  f6_add(s, f.c0, f.c1);
-  f6_mul_by_01(t, s, l0, add(l1, l4));
+  f6_addn(s, f.c0, f.c1);
+  f6_mul_by_01(t, s, l0, norm(add(l1, l4)));
   f6_sub(t, t, aa);
-  f6_sub(f.c1, t, bb);
+  f6_sub(t, t, bb);
+  f6_norm(f.c1, t);
   f6_mul_v(bb, bb);
-  f6_add(f.c0, aa, bb);
+  f6_addn(f.c0, aa, bb);
 }
 // f *= l0 + (l3 + l4 v) w          -- line shape of a D-type twist (BN254)
 template <class C>
@@ -266,21 +280,23 @@ GS_HD_NOINLINE void f12_mul_by_034(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l
   Fp6<C> aa, bb, s, t;
   f6_mul_fp2(aa, f.c0, l0);
   f6_mul_by_01(bb, f.c1, l3, l4);
-  f6_add(s, f.c0, f.c1);
-  f6_mul_by_01(t, s, add(l0, l3), l4);
+  f6_addn(s, f.c0, f.c1);
+  f6_mul_by_01(t, s, norm(add(l0, l3)), l4);
   f6_sub(t, t, aa);
-  f6_sub(f.c1, t, bb);
+  f6_sub(t, t, bb);
+  f6_norm(f.c1, t);
   f6_mul_v(bb, bb);
-  f6_add(f.c0, aa, bb);
+  f6_addn(f.c0, aa, bb);
 }
 
 // Granger-Scott squaring for elements of the cyclotomic subgroup (after the
-// easy part of the final exponentiation): 6 Fp2 squarings-worth of work.
+// easy part of the final exponentiation).
 template <class C> GS_HD void fp4_sqr(Fp2<C>& o0, Fp2<C>& o1, const Fp2<C>& a, const Fp2<C>& b) {
-  // (a + b t)^2 with t^2 = xi:  o0 = a^2 + xi b^2, o1 = 2ab
+  // (a + b t)^2 with t^2 = xi:  o0 = a^2 + xi b^2, o1 = 2ab ; outputs N
   Fp2<C> ab = mul(a, b);
-  o0 = sub(sub(mul(add(a, b), add(a, mul_xi(b))), ab), mul_xi(ab));
-  o1 = dbl(ab);
+  Fp2<C> m = mul(norm(add(a, b)), norm(add(a, mul_xi(b))));
+  o0 = norm(sub(sub(m, ab), norm(mul_xi(ab))));
+  o1 = norm(dbl(ab));
 }
 template <class C> GS_HD_NOINLINE void f12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& f) {
   Fp2<C> t0, t1, t2, t3, t4, t5;
@@ -290,20 +306,72 @@ template <class C> GS_HD_NOINLINE void f12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& 
   // z0 = 3 t0 - 2 z0 ; z1 = 3 t1 + 2 z1
   Fp2<C> z;
   z = sub(t0, f.c0.c0);
-  r.c0.c0 = add(dbl(z), t0);
+  r.c0.c0 = norm(add(dbl(z), t0));
   z = add(t1, f.c1.c1);
-  r.c1.c1 = add(dbl(z), t1);
+  r.c1.c1 = norm(add(dbl(z), t1));
   // z2 = 3 xi t5 + 2 z2 ; z3 = 3 t4 - 2 z3
-  Fp2<C> x5 = mul_xi(t5);
+  Fp2<C> x5 = norm(mul_xi(t5));
   z = add(x5, f.c1.c0);
-  r.c1.c0 = add(dbl(z), x5);
+  r.c1.c0 = norm(add(dbl(z), x5));
   z = sub(t4, f.c0.c2);
-  r.c0.c2 = add(dbl(z), t4);
+  r.c0.c2 = norm(add(dbl(z), t4));
   // z4 = 3 t2 - 2 z4 ; z5 = 3 t3 + 2 z5
   z = sub(t2, f.c0.c1);
-  r.c0.c1 = add(dbl(z), t2);
+  r.c0.c1 = norm(add(dbl(z), t2));
   z = add(t3, f.c1.c2);
-  r.c1.c2 = add(dbl(z), t3);
+  r.c1.c2 = norm(add(dbl(z), t3));
+}
+
+// bring every coefficient's VALUE back to ~[-p, p] (see vreduce in gs_fq28.cuh)
+template <class C> GS_HD_NOINLINE void f12_vreduce(Fp12<C>& f) {
+  Fp2<C>* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int i = 0; i < 6; i++) {
+    c[i]->c0 = vreduce(c[i]->c0);
+    c[i]->c1 = vreduce(c[i]->c1);
+  }
+}
+
+// ---- boundary I/O (include/gs_amd.h layout: saturated Montgomery limbs) -------
+template <class C> struct BFq {
+  uint32_t w[C::N];
+};
+template <class C> GS_HD Fp2<C> fp2_from_boundary(const BFq<C>* p) {
+  return {fq_from_boundary<C>(p[0].w), fq_from_boundary<C>(p[1].w)};
+}
+template <class C> GS_HD void fp2_to_boundary(BFq<C>* p, const Fp2<C>& a) {
+  fq_to_boundary<C>(p[0].w, a.c0);
+  fq_to_boundary<C>(p[1].w, a.c1);
+}
+template <class C> GS_HD_NOINLINE void f12_from_boundary(Fp12<C>& r, const BFq<C>* p) {
+  r.c0.c0 = fp2_from_boundary<C>(p + 0);
+  r.c0.c1 = fp2_from_boundary<C>(p + 2);
+  r.c0.c2 = fp2_from_boundary<C>(p + 4);
+  r.c1.c0 = fp2_from_boundary<C>(p + 6);
+  r.c1.c1 = fp2_from_boundary<C>(p + 8);
+  r.c1.c2 = fp2_from_boundary<C>(p + 10);
+}
+template <class C> GS_HD_NOINLINE void f12_to_boundary(BFq<C>* p, const Fp12<C>& a) {
+  fp2_to_boundary<C>(p + 0, a.c0.c0);
+  fp2_to_boundary<C>(p + 2, a.c0.c1);
+  fp2_to_boundary<C>(p + 4, a.c0.c2);
+  fp2_to_boundary<C>(p + 6, a.c1.c0);
+  fp2_to_boundary<C>(p + 8, a.c1.c1);
+  fp2_to_boundary<C>(p + 10, a.c1.c2);
+}
+// equality of two GT values through their canonical boundary forms
+template <class C> GS_HD_NOINLINE bool f12_eq(const Fp12<C>& a, const Fp12<C>& b) {
+  BFq<C> x[12], y[12];
+  f12_to_boundary<C>(x, a);
+  f12_to_boundary<C>(y, b);
+  uint32_t o = 0;
+  for (int i = 0; i < 12; i++)
+    for (int j = 0; j < C::N; j++) o |= x[i].w[j] ^ y[i].w[j];
+  return o == 0;
+}
+template <class C> GS_HD bool f12_is_one(const Fp12<C>& a) {
+  Fp12<C> o;
+  f12_one(o);
+  return f12_eq(a, o);
 }
 
 }  // namespace gs

@@ -28,7 +28,8 @@ def twin():
     if not os.path.exists(TWIN_SO) or any(os.path.getmtime(s) > os.path.getmtime(TWIN_SO) for s in srcs):
         if not os.path.exists(CLANG):
             pytest.skip("no host clang++ for the CPU twin")
-        subprocess.check_call([CLANG, "-O2", "-std=c++17", "-Wno-psabi", "-shared", "-fPIC", TWIN_SRC, "-o", TWIN_SO])
+        subprocess.check_call([CLANG, "-O2", "-std=c++17", "-Wno-psabi", "-DGS_FQ28_CHECK", "-shared", "-fPIC", TWIN_SRC,
+                               "-o", TWIN_SO])
     return ctypes.CDLL(TWIN_SO)
 
 
@@ -51,7 +52,9 @@ def test_field_ops(twin, cname):
         assert c.fq_dec(o[0]) == (a + b) % c.p
         assert c.fq_dec(o[1]) == (a - b) % c.p
         assert c.fq_dec(o[2]) == (-a) % c.p
-        assert c.fq_dec(o[3]) == a * pow(2, -1, c.p) % c.p
+        assert c.fq_dec(o[3]) == (8 * a - 5 * b) % c.p
+        assert getattr(twin, "twin_fp_is_zero_" + cname)(ptr(c.fq(a)), ptr(c.fq(a))) == 1
+        assert getattr(twin, "twin_fp_is_zero_" + cname)(ptr(c.fq(a)), ptr(c.fq(b))) == (1 if a == b else 0)
         x = int.from_bytes(rng.bytes(32), "little") % c.r
         y = int.from_bytes(rng.bytes(32), "little") % c.r
         outr = np.zeros(c.nr, dtype=np.uint64)
@@ -96,6 +99,16 @@ def test_smul_golden(twin, cname):
     assert not out.any()
     getattr(twin, "twin_g1_add_" + cname)(ptr(g1), ptr(g1), ptr(out))
     assert (out == two).all()
+    # mixed add on G2: P + P (doubling branch), P + (-P) (identity), P + O
+    two2 = c.g2(g["g2_smul"][1]["out"])
+    m2 = c.g2(g["g2_smul"][-1]["out"])
+    out2 = np.ones(4 * c.nq, dtype=np.uint64)
+    getattr(twin, "twin_g2_madd_" + cname)(ptr(g2), ptr(g2), ptr(out2))
+    assert (out2 == two2).all()
+    getattr(twin, "twin_g2_madd_" + cname)(ptr(g2), ptr(m2), ptr(out2))
+    assert not out2.any()
+    getattr(twin, "twin_g2_madd_" + cname)(ptr(g2), ptr(c.g2(None)), ptr(out2))
+    assert (out2 == g2).all()
 
 
 @pytest.mark.parametrize("cname", CURVES)

@@ -1,6 +1,8 @@
 // CPU twin of the HIP arithmetic library: the SAME headers compiled for the
 // host with clang++ (no HIP), exposed through a tiny C ABI so that pytest can
 // check the device algorithms against the golden fixtures without a GPU.
+// Built with -DGS_FQ28_CHECK: every radix-2^28 multiplication asserts its limb
+// contract and every lazy add/sub asserts that int32 limbs would not overflow.
 // Test infrastructure only -- never loaded by the product.
 #include <string.h>
 #include "../../groth_sahai_rs_amd/csrc/gs_params_bls12_381.h"
@@ -16,25 +18,29 @@ using namespace gs;
 template <class C> struct Twin {
   typedef Fq<C> F1;
   typedef Fp2<C> F2;
-  static void fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) {
-    F1 x, y;
-    memcpy(&x, a, sizeof x);
-    memcpy(&y, b, sizeof y);
-    F1 r = mul(x, y);
-    memcpy(o, &r, sizeof r);
+  static constexpr int NB = C::N * 4;  // boundary bytes of one Fq
+  static F1 ld1(const uint8_t* p) { return fq_from_boundary<C>((const uint32_t*)p); }
+  static void st1(uint8_t* p, const F1& a) { fq_to_boundary<C>((uint32_t*)p, a); }
+  static Aff<F1> ldg1(const uint8_t* p) { return {ld1(p), ld1(p + NB)}; }
+  static void stg1(uint8_t* p, const Aff<F1>& a) { st1(p, a.x); st1(p + NB, a.y); }
+  static Aff<F2> ldg2(const uint8_t* p) { return {{ld1(p), ld1(p + NB)}, {ld1(p + 2 * NB), ld1(p + 3 * NB)}}; }
+  static void stg2(uint8_t* p, const Aff<F2>& a) { st1(p, a.x.c0); st1(p + NB, a.x.c1); st1(p + 2 * NB, a.y.c0); st1(p + 3 * NB, a.y.c1); }
+
+  static void fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o) { st1(o, mul(ld1(a), ld1(b))); }
+  static void fp_inv(const uint8_t* a, uint8_t* o) { st1(o, inv(ld1(a))); }
+  static void fp_addsub(const uint8_t* a, const uint8_t* b, uint8_t* o) {  // o = [a+b, a-b, -a, 8a - 5b (lazy chain)]
+    F1 x = ld1(a), y = ld1(b);
+    st1(o, add(x, y));
+    st1(o + NB, sub(x, y));
+    st1(o + 2 * NB, neg(x));
+    F1 t = sub(norm(mul_small(x, 4)), y);   // 4x - y
+    t = sub(dbl(t), mul_small(y, 3));       // 8x - 5y
+    st1(o + 3 * NB, t);
   }
-  static void fp_inv(const uint32_t* a, uint32_t* o) {
-    F1 x;
-    memcpy(&x, a, sizeof x);
-    F1 r = inv(x);
-    memcpy(o, &r, sizeof r);
-  }
-  static void fp_addsub(const uint32_t* a, const uint32_t* b, uint32_t* o) {  // o = [a+b, a-b, -a, a/2]
-    F1 x, y;
-    memcpy(&x, a, sizeof x);
-    memcpy(&y, b, sizeof y);
-    F1 r[4] = {add(x, y), sub(x, y), neg(x), half(x)};
-    memcpy(o, r, sizeof r);
+  static int fp_is_zero(const uint8_t* a, const uint8_t* b) {  // is_zero(a - b) through the lazy path
+    F1 x = ld1(a), y = ld1(b);
+    F1 d = sub(add(x, x), add(y, y));
+    return is_zero(d) ? 1 : 0;
   }
   static void fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) {
     Fr<C> x, y;
@@ -43,42 +49,46 @@ template <class C> struct Twin {
     Fr<C> r = mul(x, y);
     memcpy(o, &r, sizeof r);
   }
-  static void g1_smul(const uint32_t* p, const uint32_t* k_mont, uint32_t* o) {
-    Aff<F1> P, R;
+  static void g1_smul(const uint8_t* p, const uint32_t* k_mont, uint8_t* o) {
+    Aff<F1> P = ldg1(p), R;
     Fr<C> k;
-    memcpy(&P, p, sizeof P);
     memcpy(&k, k_mont, sizeof k);
     Jac<F1> J;
     jac_smul(J, P, from_mont(k));
     jac_to_aff(R, J);
-    memcpy(o, &R, sizeof R);
+    stg1(o, R);
   }
-  static void g2_smul(const uint32_t* p, const uint32_t* k_mont, uint32_t* o) {
-    Aff<F2> P, R;
+  static void g2_smul(const uint8_t* p, const uint32_t* k_mont, uint8_t* o) {
+    Aff<F2> P = ldg2(p), R;
     Fr<C> k;
-    memcpy(&P, p, sizeof P);
     memcpy(&k, k_mont, sizeof k);
     Jac<F2> J;
     jac_smul(J, P, from_mont(k));
     jac_to_aff(R, J);
-    memcpy(o, &R, sizeof R);
+    stg2(o, R);
   }
-  static void g1_add(const uint32_t* p, const uint32_t* q, uint32_t* o) {
-    Aff<F1> P, Q, R;
-    memcpy(&P, p, sizeof P);
-    memcpy(&Q, q, sizeof Q);
+  static void g1_add(const uint8_t* p, const uint8_t* q, uint8_t* o) {
+    Aff<F1> P = ldg1(p), Q = ldg1(q), R;
     Jac<F1> J, K;
     jac_from_aff(J, P);
     jac_from_aff(K, Q);
     jac_add(J, J, K);
     jac_to_aff(R, J);
-    memcpy(o, &R, sizeof R);
+    stg1(o, R);
+  }
+  static void g2_madd(const uint8_t* p, const uint8_t* q, uint8_t* o) {
+    Aff<F2> P = ldg2(p), Q = ldg2(q), R;
+    Jac<F2> J;
+    jac_from_aff(J, P);
+    jac_madd(J, J, Q);
+    jac_to_aff(R, J);
+    stg2(o, R);
   }
   // op: 0 mul, 1 sqr, 2 inv, 3 conj, 4 frob1, 5 frob2, 6 frob3, 7 cyclo_sqr
-  static void fp12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* o) {
+  static void fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o) {
     Fp12<C> x, y, r;
-    memcpy(&x, a, sizeof x);
-    if (b) memcpy(&y, b, sizeof y);
+    f12_from_boundary<C>(x, (const BFq<C>*)a);
+    if (b) f12_from_boundary<C>(y, (const BFq<C>*)b);
     switch (op) {
       case 0: f12_mul(r, x, y); break;
       case 1: f12_sqr(r, x); break;
@@ -90,45 +100,42 @@ template <class C> struct Twin {
       case 7: f12_cyclo_sqr(r, x); break;
       default: r = x;
     }
-    memcpy(o, &r, sizeof r);
+    f12_to_boundary<C>((BFq<C>*)o, r);
   }
-  static void multi_pairing(int np, const uint32_t* ps, const uint32_t* qs, uint32_t* o, int do_fe) {
+  static void multi_pairing(int np, const uint8_t* ps, const uint8_t* qs, uint8_t* o, int do_fe) {
     Aff<F1>* P = new Aff<F1>[np];
     Aff<F2>* Q = new Aff<F2>[np];
     Proj2<C>* T = new Proj2<C>[np];
     bool* live = new bool[np];
-    memcpy(P, ps, sizeof(Aff<F1>) * np);
-    memcpy(Q, qs, sizeof(Aff<F2>) * np);
+    for (int i = 0; i < np; i++) {
+      P[i] = ldg1(ps + i * 2 * NB);
+      Q[i] = ldg2(qs + i * 4 * NB);
+    }
     Fp12<C> f, e;
     multi_miller(f, P, Q, np, T, live);
     if (do_fe) final_exp(e, f); else e = f;
-    memcpy(o, &e, sizeof e);
+    f12_to_boundary<C>((BFq<C>*)o, e);
     delete[] P; delete[] Q; delete[] T; delete[] live;
-  }
-  static void final_exp_only(const uint32_t* a, uint32_t* o) {
-    Fp12<C> f, e;
-    memcpy(&f, a, sizeof f);
-    final_exp(e, f);
-    memcpy(o, &e, sizeof e);
   }
 };
 
 #define EXPORT(SUF, CURVE)                                                                                        \
   extern "C" {                                                                                                    \
-  void twin_fp_mul_##SUF(const uint32_t* a, const uint32_t* b, uint32_t* o) { Twin<CURVE>::fp_mul(a, b, o); }    \
-  void twin_fp_inv_##SUF(const uint32_t* a, uint32_t* o) { Twin<CURVE>::fp_inv(a, o); }                          \
-  void twin_fp_addsub_##SUF(const uint32_t* a, const uint32_t* b, uint32_t* o) { Twin<CURVE>::fp_addsub(a, b, o); } \
+  void twin_fp_mul_##SUF(const uint8_t* a, const uint8_t* b, uint8_t* o) { Twin<CURVE>::fp_mul(a, b, o); }       \
+  void twin_fp_inv_##SUF(const uint8_t* a, uint8_t* o) { Twin<CURVE>::fp_inv(a, o); }                            \
+  void twin_fp_addsub_##SUF(const uint8_t* a, const uint8_t* b, uint8_t* o) { Twin<CURVE>::fp_addsub(a, b, o); } \
+  int twin_fp_is_zero_##SUF(const uint8_t* a, const uint8_t* b) { return Twin<CURVE>::fp_is_zero(a, b); }        \
   void twin_fr_mul_##SUF(const uint32_t* a, const uint32_t* b, uint32_t* o) { Twin<CURVE>::fr_mul(a, b, o); }    \
-  void twin_g1_smul_##SUF(const uint32_t* p, const uint32_t* k, uint32_t* o) { Twin<CURVE>::g1_smul(p, k, o); }  \
-  void twin_g2_smul_##SUF(const uint32_t* p, const uint32_t* k, uint32_t* o) { Twin<CURVE>::g2_smul(p, k, o); }  \
-  void twin_g1_add_##SUF(const uint32_t* p, const uint32_t* q, uint32_t* o) { Twin<CURVE>::g1_add(p, q, o); }    \
-  void twin_fp12_op_##SUF(int op, const uint32_t* a, const uint32_t* b, uint32_t* o) {                           \
+  void twin_g1_smul_##SUF(const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g1_smul(p, k, o); }    \
+  void twin_g2_smul_##SUF(const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g2_smul(p, k, o); }    \
+  void twin_g1_add_##SUF(const uint8_t* p, const uint8_t* q, uint8_t* o) { Twin<CURVE>::g1_add(p, q, o); }       \
+  void twin_g2_madd_##SUF(const uint8_t* p, const uint8_t* q, uint8_t* o) { Twin<CURVE>::g2_madd(p, q, o); }     \
+  void twin_fp12_op_##SUF(int op, const uint8_t* a, const uint8_t* b, uint8_t* o) {                              \
     Twin<CURVE>::fp12_op(op, a, b, o);                                                                            \
   }                                                                                                               \
-  void twin_multi_pairing_##SUF(int np, const uint32_t* ps, const uint32_t* qs, uint32_t* o, int fe) {           \
+  void twin_multi_pairing_##SUF(int np, const uint8_t* ps, const uint8_t* qs, uint8_t* o, int fe) {              \
     Twin<CURVE>::multi_pairing(np, ps, qs, o, fe);                                                                \
   }                                                                                                               \
-  void twin_final_exp_##SUF(const uint32_t* a, uint32_t* o) { Twin<CURVE>::final_exp_only(a, o); }               \
   }
 EXPORT(bls12_381, Bls12_381)
 EXPORT(bn254, Bn254)
