@@ -19,7 +19,7 @@
 namespace gs {
 
 #ifndef GS_WPE
-#define GS_WPE 1
+#define GS_WPE 2
 #endif
 constexpr int MAX_ARR = 8;
 struct ArrTab {
