@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_smul_batch(size_t n, const uint8
   Aff<F> P;
   aff_load<C>(P, p + (broadcast ? 0 : i) * AFFB(C, F));
   Jac<F> J;
-  jac_smul(J, P, from_mont(k[i]));
+  jac_smul_any<C>(J, P, from_mont(k[i]));
   Aff<F> R;
   jac_to_aff(R, J);
   aff_store<C>(out + i * AFFB(C, F), R);
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_build_tables(int nb, const uint8
   Aff<F> B;
   aff_load<C>(B, bases + b * AFFB(C, F));
   Jac<F> J;
-  jac_smul(J, B, k);
+  jac_smul(J, B, k);  // integer multiple d*2^(8w) may exceed r: plain path (endo decomposition assumes k < r)
   Aff<F> R;
   jac_to_aff(R, J);
   tab[i] = R;
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, con
   Aff<F> P;
   aff_load<C>(P, arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
   Jac<F> J;
-  jac_smul(J, P, k);
+  jac_smul_any<C>(J, P, k);
   part[e * nslots + t.slot] = J;
 }
 

@@ -54,7 +54,7 @@ template <class C> struct Twin {
     Fr<C> k;
     memcpy(&k, k_mont, sizeof k);
     Jac<F1> J;
-    jac_smul(J, P, from_mont(k));
+    jac_smul_any<C>(J, P, from_mont(k));
     jac_to_aff(R, J);
     stg1(o, R);
   }
@@ -63,7 +63,7 @@ template <class C> struct Twin {
     Fr<C> k;
     memcpy(&k, k_mont, sizeof k);
     Jac<F2> J;
-    jac_smul(J, P, from_mont(k));
+    jac_smul_any<C>(J, P, from_mont(k));
     jac_to_aff(R, J);
     stg2(o, R);
   }
