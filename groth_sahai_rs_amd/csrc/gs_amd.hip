@@ -418,8 +418,8 @@ template <class C> struct Impl {
   // --------------------------------------------------------------- verify --
   struct VerifyPlan {
     SidePlan g1;                      // PA_j (j<n) [+ PB] as Com1-shaped pairs
-    std::vector<MillerTask> mt;       // ordered by cell
-    int cb[5];
+    std::vector<MillerTask> mt;
+    CellMap cm;
     int npa;                          // Com1 elements in the PA scratch per equation
   };
 
@@ -436,7 +436,7 @@ template <class C> struct Impl {
 
   // P arrays: 0 PA scratch, 1 xcoms, 2 crs G1 consts, 3 theta
   // Q arrays: 0 ycoms, 1 B, 2 crs G2 consts, 3 pi, 4 target (MSMEG2)
-  static void build_verify(VerifyPlan& vp, int ty, int m, int n, const PoolMap& pm) {
+  static void build_verify(VerifyPlan& vp, int ty, int m, int n, const PoolMap& pm, int ch, bool twin) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
     int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     // ---- G1-side points: PA_j.a = map_a_j.a + sum_i Gamma_ij c_i.a ;  PB.a = sum_i b_i c_i.a - lin_t
@@ -471,32 +471,47 @@ template <class C> struct Impl {
       vp.npa = n + 1;
     }
     sp.nslots = slot;
-    // ---- Miller tasks per cell
+    // ---- Miller tasks.  Pairs of cell (a, b): G1 argument = component a, G2 argument = component b.
+    //  twin  : one task list per b, each lane takes `ch` (Q, P0, P1) triples and keeps two accumulators
+    //          (lines of Q computed once) -- less total work, pays off once the chip is full;
+    //  single: one task list per cell, `ch` (P, Q) pairs and one accumulator per lane -- more, shorter lanes.
     vp.mt.clear();
-    for (int cell = 0; cell < 4; cell++) {
-      int a = cell >> 1, b = cell & 1;
+    for (int cell = 0; cell < (twin ? 2 : 4); cell++) {
+      int b = twin ? cell : (cell & 1), a = twin ? 0 : (cell >> 1);
       std::vector<PairRef> pr;
-      for (int j = 0; j < n; j++) add_pair(pr, 0, 2 * j + a, 0, 0, 2 * j + b);
+      for (int j = 0; j < n; j++) add_pair(pr, 0, 2 * j + a, 0, 0, 2 * j + b);      // (PA_j.a, d_j.b)
       if (yg) {
         if (b == 1)
-          for (int i = 0; i < m; i++) add_pair(pr, 1, 2 * i + a, 0, 1, i);
+          for (int i = 0; i < m; i++) add_pair(pr, 1, 2 * i + a, 0, 1, i);          // (c_i.a, B_i)
       } else {
-        add_pair(pr, 0, 2 * n + a, 0, 2, 4 + b);  // (PB.a, W2.b)
+        add_pair(pr, 0, 2 * n + a, 0, 2, 4 + b);                                    // (PB.a, W2.b)
       }
-      for (int k = 0; k < kx; k++) add_pair(pr, 2, 2 * k + a, 1, 3, 2 * k + b);   // (-u_k.a, pi_k.b)
-      for (int l = 0; l < ky; l++) add_pair(pr, 3, 2 * l + a, 1, 2, 2 * l + b);   // (-theta_l.a, v_l.b)
-      if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 2, 4 + a, 1, 4, 0);              // (-W1.a, t)
-      vp.cb[cell] = (int)vp.mt.size();
-      for (size_t s = 0; s < pr.size(); s += MILLER_CH) {
+      for (int k = 0; k < kx; k++) add_pair(pr, 2, 2 * k + a, 1, 3, 2 * k + b);     // (-u_k.a, pi_k.b)
+      for (int l = 0; l < ky; l++) add_pair(pr, 3, 2 * l + a, 1, 2, 2 * l + b);     // (-theta_l.a, v_l.b)
+      if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 2, 4 + a, 1, 4, 0);               // (-W1.a, t)
+      int lo = (int)vp.mt.size();
+      for (size_t s = 0; s < pr.size(); s += ch) {
         MillerTask t;
         memset(&t, 0, sizeof t);
-        t.cell = (uint8_t)cell;
-        t.np = (uint8_t)((pr.size() - s) < (size_t)MILLER_CH ? (pr.size() - s) : MILLER_CH);
+        t.b = (uint8_t)b;
+        t.single = twin ? 0 : 1;
+        t.np = (uint8_t)((pr.size() - s) < (size_t)ch ? (pr.size() - s) : ch);
         for (int q = 0; q < t.np; q++) t.pr[q] = pr[s + q];
         vp.mt.push_back(t);
       }
+      int hi = (int)vp.mt.size();
+      if (twin) {
+        for (int aa = 0; aa < 2; aa++) {
+          vp.cm.lo[2 * aa + b] = lo;
+          vp.cm.hi[2 * aa + b] = hi;
+          vp.cm.sub[2 * aa + b] = aa;
+        }
+      } else {
+        vp.cm.lo[cell] = lo;
+        vp.cm.hi[cell] = hi;
+        vp.cm.sub[cell] = 0;
+      }
     }
-    vp.cb[4] = (int)vp.mt.size();
   }
 
   // shared front of both verifier modes: G1-side points + Miller partials
@@ -517,7 +532,9 @@ template <class C> struct Impl {
     RC(scratch(c, "verify.pool", N * pm.total * sizeof(S), &pool));
     RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, (const S*)G, xg ? nullptr : (const S*)A,
               yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm, (S*)pool));
-    build_verify(vp, ty, m, n, pm);
+    // triples per Miller lane: fewer, longer lanes amortise the accumulator squarings once the chip is full
+    bool twin = N >= 32768;
+    build_verify(vp, ty, m, n, pm, MILLER_CH, twin);
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
@@ -545,7 +562,7 @@ template <class C> struct Impl {
     RC(upload(c, "verify.mt", vp.mt, &dmt));
     int ntask = (int)vp.mt.size();
     void* mpart;
-    RC(scratch(c, "verify.mpart", N * ntask * sizeof(GT), &mpart));
+    RC(scratch(c, "verify.mpart", 2 * N * ntask * sizeof(GT), &mpart));
     ArrTab parr, qarr;
     memset(&parr, 0, sizeof parr);
     memset(&qarr, 0, sizeof qarr);
@@ -567,7 +584,10 @@ template <class C> struct Impl {
     qarr.stride[3] = (uint32_t)(kx * Z::COM2);
     qarr.base[4] = (const uint8_t*)target;
     qarr.stride[4] = (uint32_t)Z::G2;
-    RC(launch(c, "k_miller", k_miller<C>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
+    if (twin)
+      RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
+    else
+      RC(launch(c, "k_miller", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
     *mpart_out = mpart;
     return GS_OK;
   }
@@ -581,7 +601,7 @@ template <class C> struct Impl {
     int ntask = (int)vp.mt.size();
     void* cellok;
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
-    RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cb[0], vp.cb[1], vp.cb[2], vp.cb[3], vp.cb[4],
+    RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cm,
               (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
     RC(launch(c, "k_and4", k_and4, N, 256, N, (const uint8_t*)cellok, ok));
     return GS_OK;
@@ -616,7 +636,7 @@ template <class C> struct Impl {
     RC(scratch(c, "rlc.f", N * 4 * sizeof(GT), &pf));
     RC(scratch(c, "rlc.t", (N + 1) * sizeof(GT), &pt));
     RC(scratch(c, "rlc.tmp", (N / 2 + 8) * sizeof(GT), &tmp));
-    RC(launch(c, "k_rlc_pow", k_rlc_pow<C>, N * 4, 64, N, ntask, vp.cb[0], vp.cb[1], vp.cb[2], vp.cb[3], vp.cb[4],
+    RC(launch(c, "k_rlc_pow", k_rlc_pow<C>, N * 4, 64, N, ntask, vp.cm,
               (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, rho, (GT*)pf, (GT*)pt));
     uint8_t* a = (uint8_t*)acc;
     RC(gt_product(c, N * 4, (GT*)pf, (GT*)tmp, a));

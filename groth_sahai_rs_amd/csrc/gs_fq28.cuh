@@ -256,7 +256,7 @@ template <class C> GS_HD Fq28<C> sqr(const Fq28<C>& a) { return mul(a, a); }
 // robust a == 0 (mod p) for any lazily reduced a within the mul contract: one
 // multiplication by 1 brings the value into (-p/2, 3p/2) with unique limbs, where
 // the only multiples of p are 0 and p.
-template <class C> GS_HD bool is_zero(const Fq28<C>& a) {
+template <class C> GS_HD_NOINLINE bool is_zero_slow(const Fq28<C>& a) {
   Fq28<C> t = norm_full(mul(norm(a), fq_one<C>()));
   limb_t z = 0, e = 0;
 #pragma unroll
@@ -265,6 +265,15 @@ template <class C> GS_HD bool is_zero(const Fq28<C>& a) {
     e |= t.v[i] ^ C::P28[i];
   }
   return z == 0 || e == 0;
+}
+template <class C> GS_HD bool is_zero(const Fq28<C>& a) {
+  // cheap filter first: V = k p with |k| < 2^20 forces (V mod 2^28) * p^-1 mod 2^28 to be the small
+  // signed integer k; a non-multiple of p passes with probability ~2^-7, then the robust test decides
+  Fq28<C> t = norm_full(a);
+  uint32_t k = ((uint32_t)t.v[0] * (0u - C::P28_INV)) & (uint32_t)M28;   // p^-1 = -(-p^-1)
+  int32_t ks = (int32_t)(k << 4) >> 4;                                  // sign-extend 28 bits
+  if (ks > (1 << 20) || ks < -(1 << 20)) return false;
+  return is_zero_slow(a);
 }
 template <class C> GS_HD bool eq(const Fq28<C>& a, const Fq28<C>& b) { return is_zero(sub(a, b)); }
 

@@ -42,14 +42,19 @@ struct RedTask {
   uint16_t b0, e0, b1, e1, out_idx;
   uint8_t out_arr, pad;
 };
+// one G2 argument with its TWO G1 partners: P(a) = parr[p_arr][p_idx + a], a = 0, 1
 struct PairRef {
   uint8_t p_arr, q_arr, neg, pad;
   uint16_t p_idx, q_idx;
 };
 constexpr int MILLER_CH = 3;
 struct MillerTask {
-  uint8_t np, cell, pad0, pad1;
+  uint8_t np, b, single, pad1;  // single: only the P(0) partner is used (one accumulator)
   PairRef pr[MILLER_CH];
+};
+// where the Miller partials of cell c = 2a + b live: tasks [lo, hi), slot sub (0/1) of each task
+struct CellMap {
+  int lo[4], hi[4], sub[4];
 };
 struct PoolMap {  // offsets (in scalars) into the per-equation pool
   int RC, SC, PSI, PHI, OM, TC, RHO, SIG, XC, YC, GC, AC, BC, NT, total;
@@ -291,41 +296,65 @@ __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, con
 // --------------------------------------------------------------------------
 // pairing side
 // --------------------------------------------------------------------------
-template <class C>
+template <class C, bool TWIN>
 __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
                                                ArrTab qarr, Fp12<C>* out) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   size_t e = g / ntask;
   MillerTask t = tasks[g % ntask];
-  Aff<Fq<C>> ps[MILLER_CH];
+  Aff<Fq<C>> p0[MILLER_CH];
   Aff<Fp2<C>> qs[MILLER_CH];
   Proj2<C> ts[MILLER_CH];
-  bool live[MILLER_CH];
-  for (int k = 0; k < t.np; k++) {
-    PairRef r = t.pr[k];
-    aff_load<C>(ps[k], parr.base[r.p_arr] + e * parr.stride[r.p_arr] + (size_t)r.p_idx * AFFB(C, Fq<C>));
-    aff_load<C>(qs[k], qarr.base[r.q_arr] + e * qarr.stride[r.q_arr] + (size_t)r.q_idx * AFFB(C, Fp2<C>));
-    if (r.neg) ps[k].y = neg(ps[k].y);
+  if constexpr (TWIN) {
+    Aff<Fq<C>> p1[MILLER_CH];
+    uint8_t live[MILLER_CH];
+    for (int k = 0; k < t.np; k++) {
+      PairRef r = t.pr[k];
+      const uint8_t* pb = parr.base[r.p_arr] + e * parr.stride[r.p_arr] + (size_t)r.p_idx * AFFB(C, Fq<C>);
+      aff_load<C>(p0[k], pb);
+      aff_load<C>(p1[k], pb + AFFB(C, Fq<C>));
+      aff_load<C>(qs[k], qarr.base[r.q_arr] + e * qarr.stride[r.q_arr] + (size_t)r.q_idx * AFFB(C, Fp2<C>));
+      if (r.neg) {
+        p0[k].y = neg(p0[k].y);
+        p1[k].y = neg(p1[k].y);
+      }
+    }
+    Fp12<C> f0, f1;
+    multi_miller2(f0, f1, p0, p1, qs, t.np, ts, live);
+    out[2 * g] = f0;      // cell (0, b)
+    out[2 * g + 1] = f1;  // cell (1, b)
+  } else {
+    bool live[MILLER_CH];
+    for (int k = 0; k < t.np; k++) {
+      PairRef r = t.pr[k];
+      aff_load<C>(p0[k], parr.base[r.p_arr] + e * parr.stride[r.p_arr] + (size_t)r.p_idx * AFFB(C, Fq<C>));
+      aff_load<C>(qs[k], qarr.base[r.q_arr] + e * qarr.stride[r.q_arr] + (size_t)r.q_idx * AFFB(C, Fp2<C>));
+      if (r.neg) p0[k].y = neg(p0[k].y);
+    }
+    Fp12<C> f;
+    multi_miller(f, p0, qs, t.np, ts, live);
+    out[2 * g] = f;  // the task's own cell (slot 0)
   }
-  Fp12<C> f;
-  multi_miller(f, ps, qs, t.np, ts, live);
-  out[g] = f;
 }
 
-// cell_begin[c]..cell_begin[c+1] = the Miller tasks of cell c.  mode 0: exact
-// check (FE, compare with 1 or the PPE target) -> cellok[e*4+c].
+// Cell c = 2a + b: product of its Miller partials (CellMap), final exponentiation,
+// compare with 1 or the PPE target (verifier.rs:50-53) -> cellok[e*4+c].
+template <class C> GS_HD_NOINLINE void cell_product(Fp12<C>& f, const Fp12<C>* mpart, size_t e, int ntask, int c,
+                                                    const CellMap& cm) {
+  int lo = cm.lo[c], hi = cm.hi[c], a = cm.sub[c];
+  f = mpart[2 * (e * ntask + lo) + a];
+  for (int i = lo + 1; i < hi; i++) f12_mul(f, f, mpart[2 * (e * ntask + i) + a]);
+}
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4,
-                                              const Fp12<C>* mpart, const uint8_t* target, uint8_t* cellok) {
+__global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart,
+                                              const uint8_t* target, uint8_t* cellok) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * 4) return;
   size_t e = g >> 2;
   int c = (int)(g & 3);
-  int b = c == 0 ? cb0 : c == 1 ? cb1 : c == 2 ? cb2 : cb3;
-  int en = c == 0 ? cb1 : c == 1 ? cb2 : c == 2 ? cb3 : cb4;
-  Fp12<C> f = mpart[e * ntask + b];
-  for (int i = b + 1; i < en; i++) f12_mul(f, f, mpart[e * ntask + i]);
+  Fp12<C> f;
+  cell_product(f, mpart, e, ntask, c, cm);
   Fp12<C> r;
   final_exp(r, f);
   bool ok;
@@ -424,16 +453,14 @@ template <class C> GS_HD_NOINLINE void f12_pow_u64(Fp12<C>& r, const Fp12<C>& b,
 }
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE)
-    k_rlc_pow(size_t N, int ntask, int cb0, int cb1, int cb2, int cb3, int cb4, const Fp12<C>* mpart,
-              const uint8_t* target, const uint64_t* rho, Fp12<C>* out_f, Fp12<C>* out_t) {
+    k_rlc_pow(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart, const uint8_t* target, const uint64_t* rho,
+              Fp12<C>* out_f, Fp12<C>* out_t) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * 4) return;
   size_t e = g >> 2;
   int c = (int)(g & 3);
-  int b = c == 0 ? cb0 : c == 1 ? cb1 : c == 2 ? cb2 : cb3;
-  int en = c == 0 ? cb1 : c == 1 ? cb2 : c == 2 ? cb3 : cb4;
-  Fp12<C> f = mpart[e * ntask + b];
-  for (int i = b + 1; i < en; i++) f12_mul(f, f, mpart[e * ntask + i]);
+  Fp12<C> f;
+  cell_product(f, mpart, e, ntask, c, cm);
   Fp12<C> h;
   f12_pow_u64(h, f, rho[g]);
   out_f[g] = h;

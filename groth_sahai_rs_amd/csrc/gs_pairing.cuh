@@ -141,6 +141,72 @@ GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2
   if (C::LOOP_NEG) f12_conj(f, f);
 }
 
+// Twin multi-Miller loop: every G2 argument Q_k of the GS verification equation is
+// paired with TWO G1 arguments (the a = 0 and a = 1 components of the same
+// commitment-group element, data_structures.rs:484-502), so the tangent/chord
+// line of Q_k is computed once and evaluated at both: f0 *= l(P0_k), f1 *= l(P1_k).
+template <class C>
+GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0, Fp12<C>& f1, const Aff<Fq<C>>* p0, const Aff<Fq<C>>* p1,
+                                  const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts, uint8_t* live) {
+  f12_one(f0);
+  f12_one(f1);
+  bool any = false;
+  for (int k = 0; k < np; k++) {
+    bool q_ok = !aff_is_inf(qs[k]);
+    uint8_t l = 0;
+    if (q_ok && !aff_is_inf(p0[k])) l |= 1;
+    if (q_ok && !aff_is_inf(p1[k])) l |= 2;
+    live[k] = l;
+    any |= (l != 0);
+    ts[k].x = qs[k].x;
+    ts[k].y = qs[k].y;
+    ts[k].z = one_of<Fp2<C>>();
+  }
+  if (!any) return;
+  Line<C> l;
+  for (int i = C::LOOP_LEN - 2; i >= 0; i--) {
+    f12_sqr(f0, f0);
+    f12_sqr(f1, f1);
+    for (int k = 0; k < np; k++) {
+      if (!live[k]) continue;
+      miller_dbl(ts[k], l);
+      if (live[k] & 1) miller_ell(f0, l, p0[k]);
+      if (live[k] & 2) miller_ell(f1, l, p1[k]);
+    }
+    int d = C::LOOP[i];
+    if (d != 0) {
+      for (int k = 0; k < np; k++) {
+        if (!live[k]) continue;
+        Aff<Fp2<C>> q = qs[k];
+        if (d < 0) q.y = neg(q.y);
+        miller_add(ts[k], l, q);
+        if (live[k] & 1) miller_ell(f0, l, p0[k]);
+        if (live[k] & 2) miller_ell(f1, l, p1[k]);
+      }
+    }
+  }
+  if (C::IS_BN) {
+    for (int k = 0; k < np; k++) {
+      if (!live[k]) continue;
+      Aff<Fp2<C>> q1, q2;
+      q1.x = mul(conj(qs[k].x), frob_coeff<C>(1, 2));
+      q1.y = mul(conj(qs[k].y), frob_coeff<C>(1, 3));
+      q2.x = mul(qs[k].x, frob_coeff<C>(2, 2));
+      q2.y = neg(mul(qs[k].y, frob_coeff<C>(2, 3)));
+      miller_add(ts[k], l, q1);
+      if (live[k] & 1) miller_ell(f0, l, p0[k]);
+      if (live[k] & 2) miller_ell(f1, l, p1[k]);
+      miller_add(ts[k], l, q2);
+      if (live[k] & 1) miller_ell(f0, l, p0[k]);
+      if (live[k] & 2) miller_ell(f1, l, p1[k]);
+    }
+  }
+  if (C::LOOP_NEG) {
+    f12_conj(f0, f0);
+    f12_conj(f1, f1);
+  }
+}
+
 // f^|x| by square-and-multiply over the 64-bit curve parameter, cyclotomic
 // squarings; then conjugate if x < 0 (so the result is f^x).
 template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f) {
