@@ -603,7 +603,7 @@ template <class C> struct Impl {
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
     RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cm,
               (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
-    RC(launch(c, "k_and4", k_and4, N, 256, N, (const uint8_t*)cellok, ok));
+    RC(launch(c, "k_and4", k_and4, N, 64, N, (const uint8_t*)cellok, ok));
     return GS_OK;
   }
 

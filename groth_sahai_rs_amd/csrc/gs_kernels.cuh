@@ -19,7 +19,7 @@
 namespace gs {
 
 #ifndef GS_WPE
-#define GS_WPE 2
+#define GS_WPE 1
 #endif
 constexpr int MAX_ARR = 8;
 struct ArrTab {
