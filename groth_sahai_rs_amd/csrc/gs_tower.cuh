@@ -20,6 +20,14 @@
 #pragma once
 #include "gs_fq28.cuh"
 
+// Fp6 products inline into their Fp12 callers when GS_F6_INLINE is set (keeps the Fp6
+// temporaries in the register file instead of handing them over through memory)
+#if defined(GS_F6_INLINE)
+#define GS_F6 GS_HD
+#else
+#define GS_F6 GS_HD_NOINLINE
+#endif
+
 namespace gs {
 
 template <class C> using Fq = Fq28<C>;
@@ -129,7 +137,7 @@ template <class C> GS_HD void f6_mul_v(Fp6<C>& r, const Fp6<C>& a) {
   r.c0 = t;
 }
 // Karatsuba, 6 Fp2 multiplications.  r may alias a or b.  N in -> N out.
-template <class C> GS_HD_NOINLINE void f6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
+template <class C> GS_F6 void f6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
   Fp2<C> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1), v2 = mul(a.c2, b.c2);
   Fp2<C> t0 = sub(sub(mul_l2(add(a.c1, a.c2), add(b.c1, b.c2)), v1), v2);  // A = 3
   Fp2<C> t1 = sub(sub(mul_l2(add(a.c0, a.c1), add(b.c0, b.c1)), v0), v1);
@@ -139,7 +147,7 @@ template <class C> GS_HD_NOINLINE void f6_mul(Fp6<C>& r, const Fp6<C>& a, const 
   r.c2 = norm(add(t2, v1));
 }
 // a * (b0 + b1 v): 5 Fp2 multiplications
-template <class C> GS_HD_NOINLINE void f6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {
+template <class C> GS_F6 void f6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {
   Fp2<C> v0 = mul(a.c0, b0), v1 = mul(a.c1, b1);
   Fp2<C> t0 = sub(mul_l2(add(a.c1, a.c2), b1), v1);                        // a2*b1
   Fp2<C> t1 = sub(sub(mul_l2(add(a.c0, a.c1), add(b0, b1)), v0), v1);      // a0 b1 + a1 b0
