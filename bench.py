@@ -154,6 +154,16 @@ def main():
         avg_s = ms / max(launches, 1) / 1e3
         bpu = sum(w.bytes_per_unit() * w.N for w in wls) / N
         achieved = N * bpu / avg_s / 1e9
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+            # FETCH_SIZE doubled per the gfx950 correction), valid for the default 2^12 PPE workload only
+            if args.log2n == 12 and not args.mixed and args.curve == 0 and args.type == 0 and args.mode == "exact":
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic_2p12.json")))
+                for k, v in tj.items():
+                    if name.split(".")[0] in k and ("true" in k) == name.endswith(".twin"):
+                        traffic = v["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
         roof = {
             "bound": "hbm",
             "kernel": name,
@@ -161,7 +171,7 @@ def main():
             "peak": 8000.0,
             "unit": "GB/s",
             "frac": achieved / 8000.0,
-            "traffic": None,
+            "traffic": traffic,
             "avg_kernel_ms": ms / max(launches, 1),
             "bytes_per_unit": bpu,
             "kernel_share_of_step": ms / tot,
@@ -194,7 +204,7 @@ def main():
         res["roofline"] = roof
         if not args.no_cpu:
             threads = os.cpu_count() or 1
-            sample = args.cpu_sample or max(threads, 16)
+            sample = args.cpu_sample or max(8 * threads, 64)   # ~10-30 s of CPU work on the box's host cores
             res["cpu_baseline"] = cpu_baseline(sample, threads)
         print(json.dumps(res))
     if dist is not None:

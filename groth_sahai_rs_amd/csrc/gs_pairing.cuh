@@ -42,7 +42,7 @@ template <class C> GS_HD Fp2<C> twist_b3() {
 // classical (X3, Y3, Z3) scaled by 4 -- the same projective point, no halvings:
 //   X3 = 2XY (B - F), Y3 = (B + F)^2 - 12 E^2, Z3 = 4 B H
 // with B = Y^2, E = 3 b' Z^2, F = 3E, H = 2YZ.
-template <class C> GS_HD_NOINLINE void miller_dbl(Proj2<C>& t, Line<C>& l) {
+template <class C> GS_ML void miller_dbl(Proj2<C>& t, Line<C>& l) {
   Fp2<C> xy = mul(t.x, t.y);
   Fp2<C> b = sqr(t.y);
   Fp2<C> c = sqr(t.z);
@@ -61,7 +61,7 @@ template <class C> GS_HD_NOINLINE void miller_dbl(Proj2<C>& t, Line<C>& l) {
 }
 
 // T <- T + Q (Q affine on the twist), returns the chord line coefficients (all N).
-template <class C> GS_HD_NOINLINE void miller_add(Proj2<C>& t, Line<C>& l, const Aff<Fp2<C>>& q) {
+template <class C> GS_ML void miller_add(Proj2<C>& t, Line<C>& l, const Aff<Fp2<C>>& q) {
   Fp2<C> theta = norm(sub(t.y, mul(q.y, t.z)));
   Fp2<C> lambda = norm(sub(t.x, mul(q.x, t.z)));
   Fp2<C> c = sqr(theta);

@@ -27,6 +27,12 @@
 #else
 #define GS_F6 GS_HD_NOINLINE
 #endif
+// experiment: inline the Fp12 squaring / sparse product and the Miller steps into the loop
+#if defined(GS_MILLER_INLINE)
+#define GS_ML GS_HD
+#else
+#define GS_ML GS_HD_NOINLINE
+#endif
 
 namespace gs {
 
@@ -210,7 +216,7 @@ template <class C> GS_HD_NOINLINE void f12_mul(Fp12<C>& r, const Fp12<C>& a, con
   f6_addn(r.c0, t0, t1);
 }
 // complex squaring: 2 Fp6 multiplications
-template <class C> GS_HD_NOINLINE void f12_sqr(Fp12<C>& r, const Fp12<C>& a) {
+template <class C> GS_ML void f12_sqr(Fp12<C>& r, const Fp12<C>& a) {
   Fp6<C> v0, s0, s1, t;
   f6_mul(v0, a.c0, a.c1);
   f6_addn(s0, a.c0, a.c1);
@@ -270,7 +276,7 @@ template <class C> GS_HD_NOINLINE void f12_frob(Fp12<C>& r, const Fp12<C>& a, in
 
 // f *= (l0 + l1 v) + (l4 v) w      -- line shape of an M-type twist (BLS12-381); l* are N
 template <class C>
-GS_HD_NOINLINE void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const Fp2<C>& l4) {
+GS_ML void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const Fp2<C>& l4) {
   Fp6<C> aa, bb, s, t;
   f6_mul_by_01(aa, f.c0, l0, l1);
   f6_mul_by_1(bb, f.c1, l4);

@@ -1,0 +1,95 @@
+"""Batch-scale parity (GPU): synthetic batches in the BASELINE shapes are proved on
+the GPU and compared, equation by equation on a sample, with the C restatement of
+the reference path (oracle/gs_ref.c); the whole batch goes through the
+size-independent properties: every honest proof verifies, every corrupted one is
+rejected, batched (RLC) and exact verdicts agree, prove-only == commit_and_prove."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from gsutil import REPO
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+
+def _run(curve_id, cname, ty, N, m, n, sample):
+    import torch
+
+    import groth_sahai_rs_amd as gs
+    import gs_ref_py as ref
+    from groth_sahai_rs_amd.workload import Workload
+
+    eng = gs.Engine(curve_id, 0)
+    wl = Workload(eng, ty=ty, N=N, m=m, n=n, seed=777 + ty, corrupt_every=max(N // 4, 1))
+    wl.prove()
+    eng.sync()
+    host = lambda t: t.cpu().numpy()
+    X, Y, A, B, G, R, S, T = map(host, (wl.X, wl.Y, wl.A, wl.B, wl.Gamma, wl.R, wl.S, wl.T))
+    xc, yc, pi, th, tgt = map(host, (wl.xcoms, wl.ycoms, wl.pi, wl.theta, wl.target))
+    sh = wl.sh
+    kx, ky = sh["kx"], sh["ky"]
+    sx, sy, st = sh["sx"], sh["sy"], sh["st"]
+    cut = lambda a, e, sz: a[e * sz:(e + 1) * sz]
+    for e in sample:
+        out = ref.commit_and_prove(cname, ty, m, n, cut(X, e, m * sx), cut(Y, e, n * sy), cut(A, e, n * sx),
+                                   cut(B, e, m * sy), cut(G, e, m * n * 32), cut(R, e, m * kx * 32),
+                                   cut(S, e, n * ky * 32), cut(T, e, ky * kx * 32), wl.crs)
+        assert (out["xcoms"] == cut(xc, e, m * eng.COM1)).all(), (ty, e, "xcoms")
+        assert (out["ycoms"] == cut(yc, e, n * eng.COM2)).all(), (ty, e, "ycoms")
+        assert (out["pi"] == cut(pi, e, kx * eng.COM2)).all(), (ty, e, "pi")
+        assert (out["theta"] == cut(th, e, ky * eng.COM1)).all(), (ty, e, "theta")
+        assert ref.verify(cname, ty, m, n, cut(A, e, n * sx), cut(B, e, m * sy), cut(G, e, m * n * 32),
+                          cut(tgt, e, st), out["xcoms"], out["ycoms"], out["pi"], out["theta"], wl.crs) == 1
+    # whole batch: exact verdicts
+    wl.verify()
+    eng.sync()
+    assert wl.ok.cpu().numpy().all()
+    assert eng.gt_finalize(wl.verify_rlc().cpu().numpy()) == 1
+    bad = wl.corrupt()
+    wl.verify()
+    eng.sync()
+    ok = wl.ok.cpu().numpy()
+    assert [int(v) for v in ok] == [0 if i in set(bad) else 1 for i in range(N)]
+    assert eng.gt_finalize(wl.verify_rlc().cpu().numpy()) == 0
+    # the C oracle agrees on one corrupted proof
+    e = bad[0]
+    assert ref.verify(cname, ty, m, n, cut(A, e, n * sx), cut(B, e, m * sy), cut(G, e, m * n * 32), cut(tgt, e, st),
+                      cut(xc, e, m * eng.COM1), cut(yc, e, n * eng.COM2), cut(host(wl.pi), e, kx * eng.COM2),
+                      cut(th, e, ky * eng.COM1), wl.crs) == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("ty", [0, 1, 2, 3])
+def test_baseline_shape_batches_bls12_381(ty):
+    """m = n = 4 (BASELINE shape), 256 equations per type, 3 sampled against the C oracle."""
+    _run(0, "bls12_381", ty, 256, 4, 4, [0, 101, 255])
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (7, 5), (2, 9)])
+def test_ragged_shapes_ppe(shape):
+    m, n = shape
+    _run(0, "bls12_381", 0, 64, m, n, [0, 63])
+
+
+def test_bn254_batch():
+    _run(1, "bn254", 0, 128, 4, 4, [0, 77])
+    _run(1, "bn254", 1, 64, 3, 2, [5])
+
+
+def test_full_config1_batch_properties():
+    """BASELINE configs[1]: 2^12 PPE 4x4 -- size-independent properties only (bench.py asserts the same)."""
+    import groth_sahai_rs_amd as gs
+    from groth_sahai_rs_amd.workload import Workload
+
+    eng = gs.Engine(0, 0)
+    wl = Workload(eng, ty=0, N=4096, m=4, n=4, seed=20241221)
+    wl.prove()
+    bad = set(wl.corrupt())
+    wl.verify()
+    eng.sync()
+    ok = wl.ok.cpu().numpy()
+    assert len(bad) == 4 and [int(v) for v in ok] == [0 if i in bad else 1 for i in range(4096)]
+    eng.close()
