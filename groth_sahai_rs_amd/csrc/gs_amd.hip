@@ -150,6 +150,8 @@ template <class T> static int upload(gs_ctx* c, const char* name, const std::vec
 // one side (G1 or G2) of commit / prove expressed as engine tasks
 // ---------------------------------------------------------------------------
 struct SidePlan {
+  std::vector<GrpTask> grp;  // when tm > 1: lanes of k_var_multi (each sums <= tm consecutive var tasks)
+  int tm = 1;
   std::vector<VarTask> var;
   std::vector<FixTask> fix;
   std::vector<RedTask> red;
@@ -189,6 +191,37 @@ static RedTask mkred(int b0, int e0, int b1, int e1, int out_arr, int out_idx) {
   return r;
 }
 
+// Append the variable-base terms of ONE output point: chunks of <= tm terms share a lane
+// (and one partial slot); with tm == 1 every term is its own lane/slot.
+static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& slot) {
+  for (size_t s0 = 0; s0 < terms.size(); s0 += sp.tm) {
+    size_t n = terms.size() - s0 < (size_t)sp.tm ? terms.size() - s0 : (size_t)sp.tm;
+    GrpTask g;
+    g.first = (uint16_t)sp.var.size();
+    g.nt = (uint16_t)n;
+    g.slot = (uint16_t)slot;
+    g.pad = 0;
+    for (size_t i = 0; i < n; i++) {
+      VarTask v = terms[s0 + i];
+      v.slot = (uint16_t)slot;
+      sp.var.push_back(v);
+    }
+    sp.grp.push_back(g);
+    slot++;
+  }
+}
+// terms per lane for a side with `terms_per_output` variable terms per output and `outputs` outputs
+// per equation: the largest of {8, 4, 1} that still leaves >= 48k lanes
+static int pick_tm(size_t N, int terms_per_output, int outputs) {
+  for (int tm : {8, 4}) {
+    if (terms_per_output < 2) break;
+    if (tm == 8 && terms_per_output <= 4) continue;  // the 4-term instantiation carries smaller tables
+    int chunks = (terms_per_output + tm - 1) / tm;
+    if (N * (size_t)chunks * outputs >= 49152) return tm;
+  }
+  return 1;
+}
+
 // Build the plan of one side.
 //  nv      committed variables on this side (m for the G1 side, n for the G2 side)
 //  nc      constants paired with the OTHER side's variables that live here (len of A for G1 side = n; B for G2 = m)
@@ -220,8 +253,10 @@ static void build_side(SidePlan& sp, bool want_coms, int nv, int nc, bool group,
       sp.fix.push_back(mkfix(f0 + l * 2, tb_u(0, 0), f0 + l * 2 + 1, tb_u(1, 0), 0xFF, 0, slot++));
       int b1 = slot;
       sp.fix.push_back(mkfix(f0 + l * 2, tb_u(0, 1), f0 + l * 2 + 1, tb_u(1, 1), 0xFF, 0, slot++));
-      for (int j = 0; j < nc; j++) sp.var.push_back(mkvar(cs + j * npf + l, 1, j, slot++));
-      for (int i = 0; i < nv; i++) sp.var.push_back(mkvar(ph + l * nv + i, 0, i, slot++));
+      std::vector<VarTask> terms;
+      for (int j = 0; j < nc; j++) terms.push_back(mkvar(cs + j * npf + l, 1, j, 0));
+      for (int i = 0; i < nv; i++) terms.push_back(mkvar(ph + l * nv + i, 0, i, 0));
+      add_var_terms(sp, terms, slot);
       sp.red.push_back(mkred(b0, b1, b1, slot, 1, l));
     } else {
       sp.fix.push_back(mkfix(sg + l, tb_w(0), f0 + l, tb_u(0, 0), 0xFF, 0, slot++));
@@ -247,8 +282,20 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
   RC(scratch(c, (t + ".part").c_str(), N * sp.nslots * sizeof(Jac<F>), &part));
   RC(launch(c, (std::string("k_fix") + tag).c_str(), k_fix<C, F>, N * sp.fix.size(), 64, N * sp.fix.size(),
             (int)sp.fix.size(), dfix, arrs, pool, pool_n, tab, (Jac<F>*)part, sp.nslots));
-  RC(launch(c, (std::string("k_var") + tag).c_str(), k_var<C, F>, N * sp.var.size(), 64, N * sp.var.size(),
-            (int)sp.var.size(), dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
+  if (sp.tm <= 1) {
+    RC(launch(c, (std::string("k_var") + tag).c_str(), k_var<C, F>, N * sp.var.size(), 64, N * sp.var.size(),
+              (int)sp.var.size(), dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
+  } else {
+    const GrpTask* dgrp;
+    RC(upload(c, (t + ".grp").c_str(), sp.grp, &dgrp));
+    size_t tot = N * sp.grp.size();
+    if (sp.tm <= 4)
+      RC(launch(c, (std::string("k_var_multi4") + tag).c_str(), k_var_multi<C, F, 4>, tot, 64, tot, (int)sp.grp.size(),
+                dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
+    else
+      RC(launch(c, (std::string("k_var_multi8") + tag).c_str(), k_var_multi<C, F, 8>, tot, 64, tot, (int)sp.grp.size(),
+                dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
+  }
   RC(launch(c, (std::string("k_red") + tag).c_str(), k_red<C, F>, N * sp.red.size(), 64, N * sp.red.size(),
             (int)sp.red.size(), dred, (const Jac<F>*)part, sp.nslots, outs));
   return GS_OK;
@@ -343,6 +390,7 @@ template <class C> struct Impl {
     // G1 side: xcoms (m) + theta (ky).  constants A (len n) multiply S; Phi multiplies X; fixed part T.
     {
       SidePlan sp;
+      sp.tm = xg ? pick_tm(N, m + n, ky) : 1;
       build_side(sp, xcoms != nullptr, m, n, xg, kx, ky, pm.RC, pm.XC, pm.SC, pm.PHI, pm.TC, pm.SIG);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -363,6 +411,7 @@ template <class C> struct Impl {
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
     {
       SidePlan sp;
+      sp.tm = yg ? pick_tm(N, m + n, kx) : 1;
       build_side(sp, ycoms != nullptr, n, m, yg, ky, kx, pm.SC, pm.YC, pm.RC, pm.PSI, pm.OM, pm.RHO);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -436,12 +485,13 @@ template <class C> struct Impl {
 
   // P arrays: 0 PA scratch, 1 xcoms, 2 crs G1 consts, 3 theta
   // Q arrays: 0 ycoms, 1 B, 2 crs G2 consts, 3 pi, 4 target (MSMEG2)
-  static void build_verify(VerifyPlan& vp, int ty, int m, int n, const PoolMap& pm, int ch, bool twin) {
+  static void build_verify(VerifyPlan& vp, int ty, int m, int n, const PoolMap& pm, int ch, bool twin, int tm) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
     int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     // ---- G1-side points: PA_j.a = map_a_j.a + sum_i Gamma_ij c_i.a ;  PB.a = sum_i b_i c_i.a - lin_t
     // engine arrays: 0 = xcoms as 2m G1 points, 1 = A (group), 2 = target (MSMEG1)
     SidePlan& sp = vp.g1;
+    sp.tm = tm;
     int slot = 0;
     for (int j = 0; j < n; j++) {
       int b[2], e[2];
@@ -452,7 +502,11 @@ template <class C> struct Impl {
         } else {
           sp.fix.push_back(mkfix(pm.AC + j, tb_w(a), 0, 0xFF, 0xFF, 0, slot++));
         }
-        for (int i = 0; i < m; i++) sp.var.push_back(mkvar(pm.GC + i * n + j, 0, 2 * i + a, slot++));
+        {
+          std::vector<VarTask> terms;
+          for (int i = 0; i < m; i++) terms.push_back(mkvar(pm.GC + i * n + j, 0, 2 * i + a, 0));
+          add_var_terms(sp, terms, slot);
+        }
         e[a] = slot;
       }
       sp.red.push_back(mkred(b[0], e[0], b[1], e[1], 0, j));
@@ -462,7 +516,11 @@ template <class C> struct Impl {
       int b[2], e[2];
       for (int a = 0; a < 2; a++) {
         b[a] = slot;
-        for (int i = 0; i < m; i++) sp.var.push_back(mkvar(pm.BC + i, 0, 2 * i + a, slot++));
+        {
+          std::vector<VarTask> terms;
+          for (int i = 0; i < m; i++) terms.push_back(mkvar(pm.BC + i, 0, 2 * i + a, 0));
+          add_var_terms(sp, terms, slot);
+        }
         if (ty == GS_MSMEG1 && a == 1) sp.fix.push_back(mkfix(0, 0xFF, 0, 0xFF, 2, 0, slot++, 1));  // - t
         if (ty == GS_QUAD) sp.fix.push_back(mkfix(pm.NT, tb_w(a), 0, 0xFF, 0xFF, 0, slot++));       // (-t) W1.a
         e[a] = slot;
@@ -534,7 +592,7 @@ template <class C> struct Impl {
               yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm, (S*)pool));
     // triples per Miller lane: fewer, longer lanes amortise the accumulator squarings once the chip is full
     bool twin = N >= 32768;
-    build_verify(vp, ty, m, n, pm, MILLER_CH, twin);
+    build_verify(vp, ty, m, n, pm, MILLER_CH, twin, pick_tm(N, m, 2 * n));
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));

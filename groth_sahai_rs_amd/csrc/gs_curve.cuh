@@ -364,4 +364,124 @@ template <class C, class F> GS_HD void jac_smul_any(Jac<F>& r, const Aff<F>& p, 
     jac_smul(r, p, k);
 }
 
+// ---------------------------------------------------------------------------
+// Joint (Straus) multi-scalar multiplication  r = sum_t k_t P_t,  nt <= TMAX terms
+// per lane: ONE doubling chain shared by all terms (and by their endomorphism
+// sub-scalars), one 8-entry table per base.  Used for the Gamma-weighted inner
+// products once the batch is large enough that fewer, longer lanes still fill the chip.
+// ---------------------------------------------------------------------------
+template <class C> GS_HD void endo_apply(Jac<Fq<C>>& t, int s) {
+  if (s == 1) {
+    Fq<C> beta;
+    for (int i = 0; i < C::L; i++) beta.v[i] = C::BETA_28[i];
+    t.x = mul(t.x, beta);
+  }
+}
+template <class C> GS_HD void endo_apply(Jac<Fp2<C>>& t, int s) {
+  if (s == 1) {
+    t.x = mul(conj(t.x), fp2_const28<C>(C::PSI_X_28));
+    t.y = mul(conj(t.y), fp2_const28<C>(C::PSI_Y_28));
+    t.z = conj(t.z);
+  } else if (s == 2) {
+    Fq<C> nx, ny;
+    for (int l = 0; l < C::L; l++) {
+      nx.v[l] = C::PSI2_X_28[l];
+      ny.v[l] = C::PSI2_Y_28[l];
+    }
+    t.x = mul_fp(t.x, nx);
+    t.y = mul_fp(t.y, ny);
+  } else if (s == 3) {
+    t.x = mul(conj(t.x), fp2_const28<C>(C::PSI3_X_28));
+    t.y = mul(conj(t.y), fp2_const28<C>(C::PSI3_Y_28));
+    t.z = conj(t.z);
+  }
+}
+// sub-scalar digit streams of one term: G1 -> 2 x 33 digits, G2 -> 4 x 17 digits (endo curves)
+template <class C> GS_HD void endo_digits(int8_t* dg, const Fr<C>& k, const Jac<Fq<C>>*) {
+  uint32_t kk[8], q[8], k1[4], k2[4], lam[4];
+  for (int i = 0; i < 8; i++) kk[i] = k.v[i];
+  for (int i = 0; i < 4; i++) lam[i] = C::LAMBDA[i];
+  limb_divmod<8, 4>(q, k1, kk, lam);
+  for (int i = 0; i < 4; i++) k2[i] = q[i];
+  recode_w4_limbs<4>(dg, k1);
+  recode_w4_limbs<4>(dg + 33, k2);
+}
+template <class C> GS_HD void endo_digits(int8_t* dg, const Fr<C>& k, const Jac<Fp2<C>>*) {
+  uint32_t n[8], q[8], xa[2], d[4][2];
+  for (int i = 0; i < 8; i++) n[i] = k.v[i];
+  xa[0] = C::XABS_LIMBS[0];
+  xa[1] = C::XABS_LIMBS[1];
+  for (int j = 0; j < 3; j++) {
+    limb_divmod<8, 2>(q, d[j], n, xa);
+    for (int i = 0; i < 8; i++) n[i] = q[i];
+  }
+  d[3][0] = n[0];
+  d[3][1] = n[1];
+  for (int j = 0; j < 4; j++) recode_w4_limbs<2>(dg + 17 * j, d[j]);
+}
+template <class C, class F> struct EndoShape;  // streams per term, digits per stream, sign pattern
+template <class C> struct EndoShape<C, Fq<C>> {
+  static constexpr int NS = 2, ND = 33;
+  GS_HD static bool flip(int) { return false; }
+};
+template <class C> struct EndoShape<C, Fp2<C>> {
+  static constexpr int NS = 4, ND = 17;
+  GS_HD static bool flip(int s) { return (s & 1) != 0; }  // +Q, -psi Q, +psi^2 Q, -psi^3 Q
+};
+
+template <class C, class F, int TMAX>
+GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks, int nt) {
+  if constexpr (C::HAS_ENDO) {
+    typedef EndoShape<C, F> E;
+    Jac<F> tab[TMAX][8];
+    int8_t dg[TMAX][E::NS * E::ND];
+    for (int t = 0; t < nt; t++) {
+      smul_build_table(tab[t], ps[t]);
+      endo_digits<C>(dg[t], ks[t], (const Jac<F>*)nullptr);
+    }
+    jac_set_inf(r);
+    for (int i = E::ND - 1; i >= 0; i--) {
+      if (i != E::ND - 1) {
+        jac_dbl(r, r);
+        jac_dbl(r, r);
+        jac_dbl(r, r);
+        jac_dbl(r, r);
+      }
+      for (int t = 0; t < nt; t++)
+        for (int s = 0; s < E::NS; s++) {
+          int a = dg[t][s * E::ND + i];
+          if (a == 0) continue;
+          Jac<F> e = tab[t][(a < 0 ? -a : a) - 1];
+          endo_apply<C>(e, s);
+          if ((a < 0) != E::flip(s)) e.y = neg(e.y);
+          jac_add(r, r, e);
+        }
+    }
+  } else {
+    constexpr int ND = (FrM<C>::BITS + 3) / 4 + 1;
+    Jac<F> tab[TMAX][8];
+    int8_t dg[TMAX][ND];
+    for (int t = 0; t < nt; t++) {
+      smul_build_table(tab[t], ps[t]);
+      recode_w4<FrM<C>>(dg[t], ND, ks[t]);
+    }
+    jac_set_inf(r);
+    for (int i = ND - 1; i >= 0; i--) {
+      if (i != ND - 1) {
+        jac_dbl(r, r);
+        jac_dbl(r, r);
+        jac_dbl(r, r);
+        jac_dbl(r, r);
+      }
+      for (int t = 0; t < nt; t++) {
+        int a = dg[t][i];
+        if (a == 0) continue;
+        Jac<F> e = tab[t][(a < 0 ? -a : a) - 1];
+        if (a < 0) e.y = neg(e.y);
+        jac_add(r, r, e);
+      }
+    }
+  }
+}
+
 }  // namespace gs

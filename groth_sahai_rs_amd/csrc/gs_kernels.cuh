@@ -34,6 +34,9 @@ struct VarTask {
   uint16_t s_idx, p_idx, slot;
   uint8_t p_arr, pad;
 };
+struct GrpTask {  // nt consecutive VarTasks summed by one lane (Straus) into one slot
+  uint16_t first, nt, slot, pad;
+};
 struct FixTask {
   uint16_t s0, s1, a_idx, slot;
   uint8_t t0, t1, a_arr, a_neg;  // 0xFF = absent
@@ -235,6 +238,27 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, con
   Jac<F> J;
   jac_smul_any<C>(J, P, k);
   part[e * nslots + t.slot] = J;
+}
+
+// joint MSM: one lane = one GrpTask (<= TMAX terms sharing a doubling chain)
+template <class C, class F, int TMAX>
+__global__ void __launch_bounds__(64, GS_WPE) k_var_multi(size_t total, int ngrp, const GrpTask* grps, const VarTask* tasks,
+                                                  ArrTab arrs, const Fr<C>* pool, int pool_n, Jac<F>* part,
+                                                  int nslots) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / ngrp;
+  GrpTask gt = grps[g % ngrp];
+  Aff<F> P[TMAX];
+  Fr<C> k[TMAX];
+  for (int i = 0; i < gt.nt; i++) {
+    VarTask t = tasks[gt.first + i];
+    k[i] = pool[e * pool_n + t.s_idx];
+    aff_load<C>(P[i], arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
+  }
+  Jac<F> J;
+  jac_msm_straus<C, F, TMAX>(J, P, k, gt.nt);
+  part[e * nslots + gt.slot] = J;
 }
 
 template <class C, class F>

@@ -148,3 +148,23 @@ def test_pairing_golden(twin, cname):
         out = np.zeros(12 * c.nq, dtype=np.uint64)
         f(len(ps["x"]), ptr(P), ptr(Q), ptr(out), 1)
         assert c.f12_dec(out) == ps["out"][cell], cell
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_straus_msm_equals_left_mul_fixture(twin, cname):
+    """Joint MSM (Straus, shared doublings, endomorphism streams) against the golden
+    Matrix<Com>::left_mul fixture: out[i].c = sum_k lhs[i][k] * col[k].c"""
+    c = curve(cname)
+    lm = c.golden["left_mul"]
+    rows, k = len(lm["lhs"]), len(lm["lhs"][0])
+    for i in range(rows):
+        ks = np.concatenate([c.fr_hex(s) for s in lm["lhs"][i]])
+        for comp in range(2):
+            P1 = np.concatenate([c.g1(v[comp]) for v in lm["com1"]])
+            out = np.zeros(2 * c.nq, dtype=np.uint64)
+            getattr(twin, "twin_g1_msm_" + cname)(k, ptr(P1), ptr(ks), ptr(out))
+            assert c.g1_dec(out) == lm["out1"][i][comp]
+            P2 = np.concatenate([c.g2(v[comp]) for v in lm["com2"]])
+            out2 = np.zeros(4 * c.nq, dtype=np.uint64)
+            getattr(twin, "twin_g2_msm_" + cname)(k, ptr(P2), ptr(ks), ptr(out2))
+            assert c.g2_dec(out2) == lm["out2"][i][comp]

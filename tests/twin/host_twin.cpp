@@ -67,6 +67,35 @@ template <class C> struct Twin {
     jac_to_aff(R, J);
     stg2(o, R);
   }
+  // joint MSM over nt <= 8 terms (Straus), both groups
+  static void g1_msm(int nt, const uint8_t* p, const uint32_t* k_mont, uint8_t* o) {
+    Aff<F1> P[8], R;
+    Fr<C> k[8];
+    for (int i = 0; i < nt; i++) {
+      P[i] = ldg1(p + i * 2 * NB);
+      Fr<C> t;
+      memcpy(&t, k_mont + i * 8, sizeof t);
+      k[i] = from_mont(t);
+    }
+    Jac<F1> J;
+    jac_msm_straus<C, F1, 8>(J, P, k, nt);
+    jac_to_aff(R, J);
+    stg1(o, R);
+  }
+  static void g2_msm(int nt, const uint8_t* p, const uint32_t* k_mont, uint8_t* o) {
+    Aff<F2> P[8], R;
+    Fr<C> k[8];
+    for (int i = 0; i < nt; i++) {
+      P[i] = ldg2(p + i * 4 * NB);
+      Fr<C> t;
+      memcpy(&t, k_mont + i * 8, sizeof t);
+      k[i] = from_mont(t);
+    }
+    Jac<F2> J;
+    jac_msm_straus<C, F2, 8>(J, P, k, nt);
+    jac_to_aff(R, J);
+    stg2(o, R);
+  }
   static void g1_add(const uint8_t* p, const uint8_t* q, uint8_t* o) {
     Aff<F1> P = ldg1(p), Q = ldg1(q), R;
     Jac<F1> J, K;
@@ -128,6 +157,8 @@ template <class C> struct Twin {
   void twin_fr_mul_##SUF(const uint32_t* a, const uint32_t* b, uint32_t* o) { Twin<CURVE>::fr_mul(a, b, o); }    \
   void twin_g1_smul_##SUF(const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g1_smul(p, k, o); }    \
   void twin_g2_smul_##SUF(const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g2_smul(p, k, o); }    \
+  void twin_g1_msm_##SUF(int nt, const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g1_msm(nt, p, k, o); } \
+  void twin_g2_msm_##SUF(int nt, const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g2_msm(nt, p, k, o); } \
   void twin_g1_add_##SUF(const uint8_t* p, const uint8_t* q, uint8_t* o) { Twin<CURVE>::g1_add(p, q, o); }       \
   void twin_g2_madd_##SUF(const uint8_t* p, const uint8_t* q, uint8_t* o) { Twin<CURVE>::g2_madd(p, q, o); }     \
   void twin_fp12_op_##SUF(int op, const uint8_t* a, const uint8_t* b, uint8_t* o) {                              \
