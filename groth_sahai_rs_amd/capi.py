@@ -49,6 +49,12 @@ def load_library():
                 "groth_sahai_rs_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p
             )
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime; when both end up in one process torch's copy must be
+            # loaded first, otherwise its device discovery fails ("No HIP GPUs are available")
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _LIB = ctypes.CDLL(p)
         _LIB.gs_last_error.restype = ctypes.c_char_p
         _LIB.gs_version.restype = ctypes.c_char_p
