@@ -176,7 +176,7 @@ static VarTask mkvar(int s, int arr, int idx, int slot) {
   v.p_arr = (uint8_t)arr;
   v.p_idx = (uint16_t)idx;
   v.slot = (uint16_t)slot;
-  v.pad = 0;
+  v.neg = 0;
   return v;
 }
 static RedTask mkred(int b0, int e0, int b1, int e1, int out_arr, int out_idx) {
@@ -643,9 +643,9 @@ template <class C> struct Impl {
     qarr.base[4] = (const uint8_t*)target;
     qarr.stride[4] = (uint32_t)Z::G2;
     if (twin)
-      RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
+      RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2));
     else
-      RC(launch(c, "k_miller", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart));
+      RC(launch(c, "k_miller", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2));
     *mpart_out = mpart;
     return GS_OK;
   }
@@ -682,23 +682,175 @@ template <class C> struct Impl {
     return GS_OK;
   }
 
-  // batched verifier: acc[0] = prod_{e,cell} Miller(e,cell)^rho, acc[1] = prod_e t_e^rho (1 for non-PPE)
+  // Batched verifier.  acc[0] = prod_e prod_cells Miller(e,cell)^rho_{e,cell} (un-exponentiated),
+  // acc[1] = prod_e t_e^rho_{e,11} (1 for non-PPE).  The exponents are FOLDED INTO THE G1 ARGUMENTS:
+  //   prod_{a,b} e(P_a, Q_b)^{rho_ab} = prod_b e(rho_0b P_0 + rho_1b P_1, Q_b)
+  // so every G2 argument is paired ONCE (20 instead of 40 pairs for the 4+4 PPE), there is one
+  // accumulator per Miller lane, no per-cell exponentiation and one final exponentiation per batch.
+  // Two passes of the linear-combination engine on G1:
+  //   1. C'_ib = rho_0b c_i.0 + rho_1b c_i.1,  Th'_lb = rho_0b theta_l.0 + rho_1b theta_l.1
+  //   2. P'_jb = rho_1b A_j + sum_i Gamma_ij C'_ib   (a_j rho_ab W1.a for scalar constants),
+  //      PB'_b, U'_kb = rho_0b u_k.0 + rho_1b u_k.1, W1'_b      (Com-shaped: components b = 0, 1)
   static int verify_rlc(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
                         const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
                         const uint64_t* rho, void* acc) {
-    VerifyPlan vp;
-    void* mpart;
-    RC(verify_front(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, vp, &mpart));
-    int ntask = (int)vp.mt.size();
-    void *pf, *pt, *tmp;
-    RC(scratch(c, "rlc.f", N * 4 * sizeof(GT), &pf));
+    bool xg = x_is_group(ty), yg = y_is_group(ty);
+    int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+    PoolMap pm;
+    memset(&pm, 0, sizeof pm);
+    int o = 0;
+    pm.GC = o; o += m * n;
+    pm.BC = o; o += m;
+    pm.RH = o; o += 4;
+    pm.AR = o; o += 4 * n;
+    pm.NR = o; o += 4;
+    pm.total = o;
+    void* pool;
+    RC(scratch(c, "rlc.pool", N * pm.total * sizeof(S), &pool));
+    RC(launch(c, "k_prep_verify_rlc", k_prep_verify_rlc<C>, N, 64, N, m, n, (const S*)G, xg ? nullptr : (const S*)A,
+              yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, rho, pm, (S*)pool));
+    auto RH = [&](int a, int b) { return pm.RH + 2 * a + b; };
+    // ---- pass 1
+    int n1 = m + ky;
+    void* s1;
+    RC(scratch(c, "rlc.s1", N * n1 * Z::COM1, &s1));
+    {
+      SidePlan sp;
+      sp.tm = 4;
+      int slot = 0;
+      for (int q = 0; q < n1; q++) {
+        int arr = q < m ? 0 : 1, idx = q < m ? q : q - m;
+        int b0 = slot, e0 = 0, b1 = 0;
+        for (int b = 0; b < 2; b++) {
+          if (b == 1) { e0 = slot; b1 = slot; }
+          std::vector<VarTask> terms;
+          terms.push_back(mkvar(RH(0, b), arr, 2 * idx, 0));
+          terms.push_back(mkvar(RH(1, b), arr, 2 * idx + 1, 0));
+          add_var_terms(sp, terms, slot);
+        }
+        sp.red.push_back(mkred(b0, e0, b1, slot, 0, q));
+      }
+      sp.nslots = slot;
+      ArrTab arrs;
+      memset(&arrs, 0, sizeof arrs);
+      arrs.base[0] = (const uint8_t*)xcoms;
+      arrs.stride[0] = (uint32_t)(m * Z::COM1);
+      arrs.base[1] = (const uint8_t*)theta;
+      arrs.stride[1] = (uint32_t)(ky * Z::COM1);
+      OutTab outs;
+      memset(&outs, 0, sizeof outs);
+      outs.base[0] = (uint8_t*)s1;
+      outs.stride[0] = (uint32_t)(n1 * Z::COM1);
+      RC((run_side<C, F1>(c, ".r1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs)));
+    }
+    // ---- pass 2: elements 0..n-1 = P'_j, then [PB'] , U'_k (kx), [W1'] (MSMEG2)
+    int iPB = n, iU = n + (yg ? 0 : 1), iW = iU + kx, n2 = iW + (ty == GS_MSMEG2 ? 1 : 0);
+    void* s2;
+    RC(scratch(c, "rlc.s2", N * n2 * Z::COM1, &s2));
+    {
+      SidePlan sp;
+      sp.tm = 8;
+      int slot = 0;
+      for (int q = 0; q < n2; q++) {
+        int b0 = slot, e0 = 0, b1 = 0;
+        for (int b = 0; b < 2; b++) {
+          if (b == 1) { e0 = slot; b1 = slot; }
+          std::vector<VarTask> terms;
+          if (q < n) {
+            int j = q;
+            if (xg)
+              terms.push_back(mkvar(RH(1, b), 1, j, 0));                                        // rho_1b A_j
+            else
+              sp.fix.push_back(mkfix(pm.AR + j * 4 + 0 + b, tb_w(0), pm.AR + j * 4 + 2 + b, tb_w(1), 0xFF, 0, slot++));
+            for (int i = 0; i < m; i++) terms.push_back(mkvar(pm.GC + i * n + j, 0, 2 * i + b, 0));  // Gamma_ij C'_ib
+          } else if (!yg && q == iPB) {
+            for (int i = 0; i < m; i++) terms.push_back(mkvar(pm.BC + i, 0, 2 * i + b, 0));          // b_i C'_ib
+            if (ty == GS_MSMEG1) {
+              VarTask v = mkvar(RH(1, b), 2, 0, 0);                                                  // - rho_1b t
+              v.neg = 1;
+              terms.push_back(v);
+            }
+            if (ty == GS_QUAD) sp.fix.push_back(mkfix(pm.NR + 0 + b, tb_w(0), pm.NR + 2 + b, tb_w(1), 0xFF, 0, slot++));
+          } else if (q >= iU && q < iU + kx) {
+            int k = q - iU;
+            sp.fix.push_back(mkfix(RH(0, b), tb_u(k, 0), RH(1, b), tb_u(k, 1), 0xFF, 0, slot++));
+          } else {  // W1' (MSMEG2)
+            sp.fix.push_back(mkfix(RH(0, b), tb_w(0), RH(1, b), tb_w(1), 0xFF, 0, slot++));
+          }
+          if (!terms.empty()) add_var_terms(sp, terms, slot);
+        }
+        sp.red.push_back(mkred(b0, e0, b1, slot, 0, q));
+      }
+      sp.nslots = slot;
+      ArrTab arrs;
+      memset(&arrs, 0, sizeof arrs);
+      arrs.base[0] = (const uint8_t*)s1;
+      arrs.stride[0] = (uint32_t)(n1 * Z::COM1);
+      if (xg) {
+        arrs.base[1] = (const uint8_t*)A;
+        arrs.stride[1] = (uint32_t)(n * Z::G1);
+      }
+      if (ty == GS_MSMEG1) {
+        arrs.base[2] = (const uint8_t*)target;
+        arrs.stride[2] = (uint32_t)Z::G1;
+      }
+      OutTab outs;
+      memset(&outs, 0, sizeof outs);
+      outs.base[0] = (uint8_t*)s2;
+      outs.stride[0] = (uint32_t)(n2 * Z::COM1);
+      RC((run_side<C, F1>(c, ".r2", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs)));
+    }
+    // ---- Miller: every G2 argument once.  P arrays: 0 = S2, 1 = S1.  Q arrays: 0 ycoms, 1 B, 2 crs, 3 pi, 4 target
+    std::vector<PairRef> pr;
+    for (int b = 0; b < 2; b++) {
+      for (int j = 0; j < n; j++) add_pair(pr, 0, 2 * j + b, 0, 0, 2 * j + b);
+      if (yg) {
+        if (b == 1)
+          for (int i = 0; i < m; i++) add_pair(pr, 1, 2 * i + 1, 0, 1, i);
+      } else {
+        add_pair(pr, 0, 2 * iPB + b, 0, 2, 4 + b);
+      }
+      for (int k = 0; k < kx; k++) add_pair(pr, 0, 2 * (iU + k) + b, 1, 3, 2 * k + b);
+      for (int l = 0; l < ky; l++) add_pair(pr, 1, 2 * (m + l) + b, 1, 2, 2 * l + b);
+      if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 0, 2 * iW + 1, 1, 4, 0);
+    }
+    std::vector<MillerTask> mt;
+    for (size_t s0 = 0; s0 < pr.size(); s0 += MILLER_CH) {
+      MillerTask t;
+      memset(&t, 0, sizeof t);
+      t.single = 1;
+      t.np = (uint8_t)((pr.size() - s0) < (size_t)MILLER_CH ? (pr.size() - s0) : MILLER_CH);
+      for (int q = 0; q < t.np; q++) t.pr[q] = pr[s0 + q];
+      mt.push_back(t);
+    }
+    const MillerTask* dmt;
+    RC(upload(c, "rlc.mt", mt, &dmt));
+    int ntask = (int)mt.size();
+    void *mpart, *pt, *tmp;
+    RC(scratch(c, "rlc.mpart", N * ntask * sizeof(GT), &mpart));
     RC(scratch(c, "rlc.t", (N + 1) * sizeof(GT), &pt));
-    RC(scratch(c, "rlc.tmp", (N / 2 + 8) * sizeof(GT), &tmp));
-    RC(launch(c, "k_rlc_pow", k_rlc_pow<C>, N * 4, 64, N, ntask, vp.cm,
-              (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, rho, (GT*)pf, (GT*)pt));
+    RC(scratch(c, "rlc.tmp", (N * ntask / 4 + 8) * sizeof(GT), &tmp));
+    ArrTab parr, qarr;
+    memset(&parr, 0, sizeof parr);
+    memset(&qarr, 0, sizeof qarr);
+    parr.base[0] = (const uint8_t*)s2;
+    parr.stride[0] = (uint32_t)(n2 * Z::COM1);
+    parr.base[1] = (const uint8_t*)s1;
+    parr.stride[1] = (uint32_t)(n1 * Z::COM1);
+    qarr.base[0] = (const uint8_t*)ycoms;
+    qarr.stride[0] = (uint32_t)(n * Z::COM2);
+    qarr.base[1] = (const uint8_t*)B;
+    qarr.stride[1] = (uint32_t)(m * Z::G2);
+    qarr.base[2] = (const uint8_t*)c->crs_g2.p;
+    qarr.base[3] = (const uint8_t*)pi;
+    qarr.stride[3] = (uint32_t)(kx * Z::COM2);
+    qarr.base[4] = (const uint8_t*)target;
+    qarr.stride[4] = (uint32_t)Z::G2;
+    RC(launch(c, "k_miller.rlc", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 1));
     uint8_t* a = (uint8_t*)acc;
-    RC(gt_product(c, N * 4, (GT*)pf, (GT*)tmp, a));
+    RC(gt_product(c, N * ntask, (GT*)mpart, (GT*)tmp, a));
     if (ty == GS_PPE) {
+      RC(launch(c, "k_rlc_tpow", k_rlc_tpow<C>, N, 64, N, (const uint8_t*)target, rho, (GT*)pt));
       RC(gt_product(c, N, (GT*)pt, (GT*)tmp, a + Z::GT));
     } else {
       RC(launch(c, "k_gt_set_one", k_gt_set_one<C>, 1, 64, (GT*)pt));

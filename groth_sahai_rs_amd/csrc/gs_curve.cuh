@@ -440,8 +440,13 @@ GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks,
       endo_digits<C>(dg[t], ks[t], (const Jac<F>*)nullptr);
     }
     jac_set_inf(r);
-    for (int i = E::ND - 1; i >= 0; i--) {
-      if (i != E::ND - 1) {
+    int top = 0;  // highest window with a non-zero digit: short scalars skip their leading doublings
+    for (int t = 0; t < nt; t++)
+      for (int s = 0; s < E::NS; s++)
+        for (int i = E::ND - 1; i > top; i--)
+          if (dg[t][s * E::ND + i] != 0) top = i;
+    for (int i = top; i >= 0; i--) {
+      if (i != top) {
         jac_dbl(r, r);
         jac_dbl(r, r);
         jac_dbl(r, r);
@@ -466,8 +471,12 @@ GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks,
       recode_w4<FrM<C>>(dg[t], ND, ks[t]);
     }
     jac_set_inf(r);
-    for (int i = ND - 1; i >= 0; i--) {
-      if (i != ND - 1) {
+    int top = 0;
+    for (int t = 0; t < nt; t++)
+      for (int i = ND - 1; i > top; i--)
+        if (dg[t][i] != 0) top = i;
+    for (int i = top; i >= 0; i--) {
+      if (i != top) {
         jac_dbl(r, r);
         jac_dbl(r, r);
         jac_dbl(r, r);

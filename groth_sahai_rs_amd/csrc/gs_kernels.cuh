@@ -32,7 +32,7 @@ struct OutTab {
 };
 struct VarTask {
   uint16_t s_idx, p_idx, slot;
-  uint8_t p_arr, pad;
+  uint8_t p_arr, neg;  // neg: use -P
 };
 struct GrpTask {  // nt consecutive VarTasks summed by one lane (Straus) into one slot
   uint16_t first, nt, slot, pad;
@@ -60,7 +60,7 @@ struct CellMap {
   int lo[4], hi[4], sub[4];
 };
 struct PoolMap {  // offsets (in scalars) into the per-equation pool
-  int RC, SC, PSI, PHI, OM, TC, RHO, SIG, XC, YC, GC, AC, BC, NT, total;
+  int RC, SC, PSI, PHI, OM, TC, RHO, SIG, XC, YC, GC, AC, BC, NT, RH, AR, NR, total;
 };
 
 template <class T> __device__ __forceinline__ T ld(const uint8_t* p) { return *reinterpret_cast<const T*>(p); }
@@ -222,6 +222,66 @@ __global__ void __launch_bounds__(64, GS_WPE) k_prep_verify(size_t N, int m, int
   if (tq) P[pm.NT] = from_mont(neg(tq[e]));
 }
 
+template <class C> GS_HD_NOINLINE void f12_pow_u64(Fp12<C>& r, const Fp12<C>& b, uint64_t k) {
+  Fp12<C> acc;
+  f12_one(acc);
+  bool started = false;
+  for (int i = 63; i >= 0; i--) {
+    if (started) f12_sqr(acc, acc);
+    if ((k >> i) & 1) {
+      if (started)
+        f12_mul(acc, acc, b);
+      else
+        acc = b;
+      started = true;
+    }
+  }
+  r = acc;
+}
+
+// Fr preparation for the batched verifier with the random exponents folded into the G1
+// arguments: rho[e][2a+b] (64-bit) -> canonical RH[2a+b]; x-scalar types also need
+// a_j*rho_ab (AR[(j*2+a)*2+b]); QuadEqu needs (-t)*rho_ab (NR[a*2+b]).
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE)
+    k_prep_verify_rlc(size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as, const Fr<C>* bs, const Fr<C>* tq,
+                      const uint64_t* rho, PoolMap pm, Fr<C>* pool) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  Fr<C>* P = pool + e * pm.total;
+  for (int i = 0; i < m * n; i++) P[pm.GC + i] = from_mont(G[e * m * n + i]);
+  if (bs)
+    for (int i = 0; i < m; i++) P[pm.BC + i] = from_mont(bs[e * m + i]);
+  Fr<C> rm[4];
+  for (int c = 0; c < 4; c++) {
+    Fr<C> r = fzero<FrM<C>>();
+    uint64_t v = rho[e * 4 + c];
+    r.v[0] = (uint32_t)v;
+    r.v[1] = (uint32_t)(v >> 32);
+    P[pm.RH + c] = r;      // canonical (rho < 2^64 < r)
+    rm[c] = to_mont(r);
+  }
+  if (as)
+    for (int j = 0; j < n; j++)
+      for (int c = 0; c < 4; c++) P[pm.AR + j * 4 + c] = from_mont(mul(as[e * n + j], rm[c]));
+  if (tq) {
+    Fr<C> nt = neg(tq[e]);
+    for (int c = 0; c < 4; c++) P[pm.NR + c] = from_mont(mul(nt, rm[c]));
+  }
+}
+
+// out_t[e] = t_e^(rho[e][3]) for the PPE target cell (boundary in, internal out)
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE) k_rlc_tpow(size_t N, const uint8_t* target, const uint64_t* rho,
+                                                 Fp12<C>* out_t) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  Fp12<C> t, h;
+  f12_from_boundary<C>(t, reinterpret_cast<const BFq<C>*>(target) + 12 * e);
+  f12_pow_u64(h, t, rho[e * 4 + 3]);
+  out_t[e] = h;
+}
+
 // --------------------------------------------------------------------------
 // linear-combination engine
 // --------------------------------------------------------------------------
@@ -235,6 +295,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, con
   Fr<C> k = pool[e * pool_n + t.s_idx];
   Aff<F> P;
   aff_load<C>(P, arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
+  if (t.neg) P.y = neg(P.y);
   Jac<F> J;
   jac_smul_any<C>(J, P, k);
   part[e * nslots + t.slot] = J;
@@ -255,6 +316,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var_multi(size_t total, int ngrp
     VarTask t = tasks[gt.first + i];
     k[i] = pool[e * pool_n + t.s_idx];
     aff_load<C>(P[i], arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
+    if (t.neg) P[i].y = neg(P[i].y);
   }
   Jac<F> J;
   jac_msm_straus<C, F, TMAX>(J, P, k, gt.nt);
@@ -322,7 +384,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, con
 // --------------------------------------------------------------------------
 template <class C, bool TWIN>
 __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
-                                               ArrTab qarr, Fp12<C>* out) {
+                                               ArrTab qarr, Fp12<C>* out, int ostride) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   size_t e = g / ntask;
@@ -358,7 +420,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, 
     }
     Fp12<C> f;
     multi_miller(f, p0, qs, t.np, ts, live);
-    out[2 * g] = f;  // the task's own cell (slot 0)
+    out[(size_t)ostride * g] = f;  // the task's own cell (slot 0 of 2), or densely packed (batched verifier)
   }
 }
 
@@ -459,22 +521,6 @@ __global__ void __launch_bounds__(64, GS_WPE) k_gt_pow(size_t n, const uint8_t* 
 // lane (e, c): g = product of the cell's Miller partials (NOT exponentiated);
 // out_f[e*4+c] = g^rho[e*4+c]; for the PPE target cell also out_t[e] = t^rho.
 // The whole batch then needs ONE final exponentiation:  FE(prod out_f) == prod out_t.
-template <class C> GS_HD_NOINLINE void f12_pow_u64(Fp12<C>& r, const Fp12<C>& b, uint64_t k) {
-  Fp12<C> acc;
-  f12_one(acc);
-  bool started = false;
-  for (int i = 63; i >= 0; i--) {
-    if (started) f12_sqr(acc, acc);
-    if ((k >> i) & 1) {
-      if (started)
-        f12_mul(acc, acc, b);
-      else
-        acc = b;
-      started = true;
-    }
-  }
-  r = acc;
-}
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE)
     k_rlc_pow(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart, const uint8_t* target, const uint64_t* rho,
