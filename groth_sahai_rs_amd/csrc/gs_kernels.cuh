@@ -517,30 +517,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_gt_pow(size_t n, const uint8_t* 
   f12_to_boundary<C>(reinterpret_cast<BFq<C>*>(out) + 12 * g, acc);
 }
 
-// ---- batched (random-linear-combination) verifier -------------------------------
-// lane (e, c): g = product of the cell's Miller partials (NOT exponentiated);
-// out_f[e*4+c] = g^rho[e*4+c]; for the PPE target cell also out_t[e] = t^rho.
-// The whole batch then needs ONE final exponentiation:  FE(prod out_f) == prod out_t.
-template <class C>
-__global__ void __launch_bounds__(64, GS_WPE)
-    k_rlc_pow(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart, const uint8_t* target, const uint64_t* rho,
-              Fp12<C>* out_f, Fp12<C>* out_t) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= N * 4) return;
-  size_t e = g >> 2;
-  int c = (int)(g & 3);
-  Fp12<C> f;
-  cell_product(f, mpart, e, ntask, c, cm);
-  Fp12<C> h;
-  f12_pow_u64(h, f, rho[g]);
-  out_f[g] = h;
-  if (c == 3 && target) {
-    Fp12<C> t;
-    f12_from_boundary<C>(t, reinterpret_cast<const BFq<C>*>(target) + 12 * e);
-    f12_pow_u64(h, t, rho[g]);
-    out_t[e] = h;
-  }
-}
+// ---- batched (random-linear-combination) verifier: tree product + one final exponentiation ----
 // out[i] = product of in[i*K .. min((i+1)*K, n_in))
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE) k_gt_prod(size_t n_in, const Fp12<C>* in, size_t n_out, Fp12<C>* out,
