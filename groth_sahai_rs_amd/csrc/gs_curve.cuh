@@ -9,6 +9,14 @@
 #pragma once
 #include "gs_tower.cuh"
 
+// experiment/option: inline the Jacobian formulas into the scalar-multiplication loops so that the
+// running point stays in the register file (single call sites: the loops below are not unrolled)
+#if defined(GS_JAC_INLINE)
+#define GS_JAC GS_HD
+#else
+#define GS_JAC GS_HD_NOINLINE
+#endif
+
 namespace gs {
 
 template <class F> struct Aff {
@@ -43,7 +51,7 @@ template <class F> GS_HD void aff_neg(Aff<F>& r, const Aff<F>& p) {
 // the lazy intermediates (gs_tower.cuh header).
 
 // dbl-2009-l: 2M + 5S
-template <class F> GS_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+template <class F> GS_JAC void jac_dbl(Jac<F>& r, const Jac<F>& p) {
   F a = sqr(p.x), b = sqr(p.y), c = sqr(b);
   F d = norm(dbl(sub(sub(sqr_l2(add(p.x, b)), a), c)));  // 2 * 3 = 6 -> N
   F e = norm(add(dbl(a), a));                            // 3 -> N
@@ -57,7 +65,7 @@ template <class F> GS_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
 }
 
 // madd-2007-bl with full edge-case handling: r = p + q (q affine)
-template <class F> GS_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
+template <class F> GS_JAC void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   if (aff_is_inf(q)) {
     r = p;
     return;
@@ -95,7 +103,7 @@ template <class F> GS_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, cons
 }
 
 // add-2007-bl with full edge-case handling: r = p + q
-template <class F> GS_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+template <class F> GS_JAC void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   if (is_zero_limbs(q.z)) {
     r = p;
     return;
@@ -155,13 +163,14 @@ template <class F> GS_HD void jac_to_aff(Aff<F>& r, const Jac<F>& p) {
 // `k` is a canonical (non-Montgomery) scalar.  tab[i] = (i+1) * P, i = 0..7.
 template <class F> GS_HD_NOINLINE void smul_build_table(Jac<F>* tab, const Aff<F>& p) {
   jac_from_aff(tab[0], p);
-  jac_dbl(tab[1], tab[0]);
-  jac_madd(tab[2], tab[1], p);
-  jac_dbl(tab[3], tab[1]);
-  jac_madd(tab[4], tab[3], p);
-  jac_dbl(tab[5], tab[2]);
-  jac_madd(tab[6], tab[5], p);
-  jac_dbl(tab[7], tab[3]);
+  // k even: kP = 2 (k/2)P ; k odd: kP = (k-1)P + P   (one doubling and one mixed-add call site)
+#pragma unroll 1
+  for (int k = 2; k <= 8; k++) {
+    if (k & 1)
+      jac_madd(tab[k - 1], tab[k - 2], p);
+    else
+      jac_dbl(tab[k - 1], tab[k / 2 - 1]);
+  }
 }
 
 // Recode a canonical scalar of NB bits into ceil((NB+1)/4) signed digits
@@ -193,10 +202,8 @@ template <class F, class M> GS_HD_NOINLINE void jac_smul(Jac<F>& r, const Aff<F>
   jac_set_inf(r);
   for (int i = ND - 1; i >= 0; i--) {
     if (i != ND - 1) {
-      jac_dbl(r, r);
-      jac_dbl(r, r);
-      jac_dbl(r, r);
-      jac_dbl(r, r);
+#pragma unroll 1
+      for (int d4 = 0; d4 < 4; d4++) jac_dbl(r, r);
     }
     int d = dg[i];
     if (d != 0) {
@@ -275,10 +282,8 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fq<C>>& r, const Aff<Fq
   jac_set_inf(r);
   for (int i = 32; i >= 0; i--) {
     if (i != 32) {
-      jac_dbl(r, r);
-      jac_dbl(r, r);
-      jac_dbl(r, r);
-      jac_dbl(r, r);
+#pragma unroll 1
+      for (int d4 = 0; d4 < 4; d4++) jac_dbl(r, r);
     }
     int a = d1[i];
     if (a != 0) {
@@ -323,10 +328,8 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fp2<C>>& r, const Aff<F
   jac_set_inf(r);
   for (int i = 16; i >= 0; i--) {
     if (i != 16) {
-      jac_dbl(r, r);
-      jac_dbl(r, r);
-      jac_dbl(r, r);
-      jac_dbl(r, r);
+#pragma unroll 1
+      for (int d4 = 0; d4 < 4; d4++) jac_dbl(r, r);
     }
     for (int j = 0; j < 4; j++) {
       int a = dg[j][i];
@@ -447,10 +450,8 @@ GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks,
           if (dg[t][s * E::ND + i] != 0) top = i;
     for (int i = top; i >= 0; i--) {
       if (i != top) {
-        jac_dbl(r, r);
-        jac_dbl(r, r);
-        jac_dbl(r, r);
-        jac_dbl(r, r);
+#pragma unroll 1
+        for (int d4 = 0; d4 < 4; d4++) jac_dbl(r, r);
       }
       for (int t = 0; t < nt; t++)
         for (int s = 0; s < E::NS; s++) {
@@ -477,10 +478,8 @@ GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks,
         if (dg[t][i] != 0) top = i;
     for (int i = top; i >= 0; i--) {
       if (i != top) {
-        jac_dbl(r, r);
-        jac_dbl(r, r);
-        jac_dbl(r, r);
-        jac_dbl(r, r);
+#pragma unroll 1
+        for (int d4 = 0; d4 < 4; d4++) jac_dbl(r, r);
       }
       for (int t = 0; t < nt; t++) {
         int a = dg[t][i];
