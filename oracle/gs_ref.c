@@ -811,6 +811,8 @@ int ref_verify(int ty, int m, int n, const void* A, const void* B, const void* G
   return verify(ty, m, n, A, B, (const fr*)G, target, (const com1*)xc, (const com2*)yc, (const com2*)pi,
                 (const com1*)theta, (const crs_t*)crs);
 }
+/* Matrix<Fr>::right_mul (data_structures.rs:824-869): out (ar x bc) = a (ar x ac) * b (ac x bc), Montgomery Fr */
+void ref_fr_matmul(int ar, int ac, int bc, const void* a, const void* b, void* out) { fr_matmul((fr*)out, (const fr*)a, ar, ac, (const fr*)b, bc); }
 u64 ref_fpmul_count(int reset) { u64 v = g_fpmul_count; if (reset) g_fpmul_count = 0; return v; }
 
 /* ------------------------------------------------ self-contained bench --- */

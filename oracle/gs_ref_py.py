@@ -92,3 +92,9 @@ def bench_ppe(units, m=4, n=4, threads=1, seed=20241220, curve="bls12_381"):
     t = lib(curve).ref_bench_ppe(units, m, n, threads, ctypes.c_uint64(seed), ctypes.byref(ok), ctypes.byref(fpm))
     bench_ppe.last_fpmuls = int(fpm.value)
     return float(t), units, bool(ok.value)
+
+
+def fr_matmul(curve, ar, ac, bc, a, b):
+    out = np.zeros(ar * bc * 32, np.uint8)
+    lib(curve).ref_fr_matmul(ar, ac, bc, _p(_u8(a)), _p(_u8(b)), _p(out))
+    return out

@@ -167,3 +167,63 @@ def test_rlc_batched_verifier(engines, cname):
             bad_last[6][3] ^= 1
             _, acc_c = e.verify_batch_rlc(ty, 1, m, n, *bad_last, rho[8:])
             assert e.gt_finalize(np.concatenate([acc_a, acc_c])) == 0
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_reference_algebraic_properties(engines, cname):
+    """Properties the reference's own unit/integration tests assert, through the L2 hooks:
+      * "1*4 + 2*5 + 3*6 = 32 in the exponent" for Com matrices      data_structures.rs:1951-2006
+      * Com::scalar_mul == component-wise group scalar mul            data_structures.rs:1235-1265
+      * iota-map / pairing commutativity for PPE and the scalar maps  tests/commit.rs:22-85
+      * pairing with an identity argument is the GT identity          data_structures.rs:1313-1343"""
+    c, e = engines[cname]
+    crs = c.golden["crs"]
+    g1, g2 = c.g1(crs["g1"]), c.g2(crs["g2"])
+    frs = lambda vals: np.stack([c.fr(v) for v in vals])
+    # k*g for k = 4, 5, 6, 32
+    m1 = e.g_mul_batch(1, g1, frs([4, 5, 6, 32, 7]), broadcast=True)
+    m2 = e.g_mul_batch(2, g2, frs([4, 5, 6, 32, 7]), broadcast=True)
+    col1 = np.concatenate([np.concatenate([m1[i], m1[i]]) for i in range(3)])  # Com1 (kg, kg)
+    col2 = np.concatenate([np.concatenate([m2[i], m2[i]]) for i in range(3)])
+    lhs = frs([1, 2, 3])
+    o1 = e.mat_left_mul(1, 1, 3, lhs, col1)[0]
+    o2 = e.mat_left_mul(2, 1, 3, lhs, col2)[0]
+    assert (o1 == np.concatenate([m1[3], m1[3]])).all() and (o2 == np.concatenate([m2[3], m2[3]])).all()
+    # scalar_mul of a Com element == component-wise smul
+    com = np.concatenate([m1[0], m1[1]])  # (4g, 5g)
+    out = e.mat_left_mul(1, 1, 1, frs([7]), com)[0].reshape(2, -1)
+    want = e.g_mul_batch(1, np.concatenate([m1[0], m1[1]]), frs([7, 7]))
+    assert (out[0] == want[0]).all() and (out[1] == want[1]).all()
+    # PPE commutativity: pairing(iota1(a1), iota2(a2)) == iota_T(e(a1, a2)) = (1, 1, 1, e(a1,a2))
+    a1, a2 = m1[0], m2[1]
+    zero1, zero2 = np.zeros_like(a1), np.zeros_like(a2)
+    cells = e.pairing_sum(1, np.concatenate([zero1, a1]), np.concatenate([zero2, a2]))
+    one = c.f12(["1"] + ["0"] * 11).view(np.uint8)
+    at = e.multi_pairing_batch(1, 1, a1, a2)[0]
+    assert (cells[0] == one).all() and (cells[1] == one).all() and (cells[2] == one).all() and (cells[3] == at).all()
+    # scalar maps: iota2'(y) = y*W2 is the scalar commitment with zero randomness (commit.rs:225-256)
+    y, x = 5, 4
+    w2y = e.commit("fr_b2", frs([y]), frs([0]))[0]            # y * W2
+    w1x = e.commit("fr_b1", frs([x]), frs([0]))[0]            # x * W1
+    w2_1 = e.commit("fr_b2", frs([1]), frs([0]))[0]           # W2
+    w1_1 = e.commit("fr_b1", frs([1]), frs([0]))[0]           # W1
+    # MSMEG1: pairing(iota1(a1), iota2'(y)) == pairing(iota1(y*a1), W2)          (tests/commit.rs:37-52)
+    ya1 = e.g_mul_batch(1, a1, frs([y]))[0]
+    l = e.pairing_sum(1, np.concatenate([zero1, a1]), w2y)
+    r = e.pairing_sum(1, np.concatenate([zero1, ya1]), w2_1)
+    assert (l == r).all()
+    # MSMEG2: pairing(iota1'(x), iota2(a2)) == pairing(W1, iota2(x*a2))          (tests/commit.rs:54-69)
+    xa2 = e.g_mul_batch(2, a2, frs([x]))[0]
+    l = e.pairing_sum(1, w1x, np.concatenate([zero2, a2]))
+    r = e.pairing_sum(1, w1_1, np.concatenate([zero2, xa2]))
+    assert (l == r).all()
+    # Quad: pairing(iota1'(x), iota2'(y)) == pairing(W1, (x*y) * W2)              (tests/commit.rs:71-85)
+    w2xy = e.commit("fr_b2", frs([x * y]), frs([0]))[0]
+    l = e.pairing_sum(1, w1x, w2y)
+    r = e.pairing_sum(1, w1_1, w2xy)
+    assert (l == r).all()
+    # identity arguments give the GT identity; empty sum too
+    cells = e.pairing_sum(1, np.concatenate([zero1, zero1]), np.concatenate([a2, a2]))
+    assert all((cells[i] == one).all() for i in range(4))
+    cells = e.pairing_sum(0, np.zeros(0, np.uint8), np.zeros(0, np.uint8))
+    assert all((cells[i] == one).all() for i in range(4))

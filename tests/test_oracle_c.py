@@ -84,3 +84,14 @@ def test_cases(cname):
 def test_bench_entry_small():
     t, units, ok = ref.bench_ppe(2, 2, 2, 2)
     assert ok and units == 2 and t > 0
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_field_matrix_kat(cname):
+    """data_structures.rs:1726-1947: [[1,2,3],[4,5,6]] * [[7..10],[11..14],[15..18]] =
+    [[74,80,86,92],[173,188,203,218]] (the Matrix<Fr> product behind R^T Gamma, Psi S, S^T Gamma^T)."""
+    c = curve(cname)
+    a = np.concatenate([c.fr(v) for v in (1, 2, 3, 4, 5, 6)])
+    b = np.concatenate([c.fr(v) for v in range(7, 19)])
+    out = ref.fr_matmul(cname, 2, 3, 4, a, b).view(np.uint64).reshape(8, 4)
+    assert [c.fr_dec(o) for o in out] == [74, 80, 86, 92, 173, 188, 203, 218]
