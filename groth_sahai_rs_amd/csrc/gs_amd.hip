@@ -160,34 +160,35 @@ struct SidePlan {
 
 static FixTask mkfix(int s0, int t0, int s1, int t1, int a_arr, int a_idx, int slot, int a_neg = 0) {
   FixTask f;
-  f.s0 = (uint16_t)s0;
-  f.s1 = (uint16_t)s1;
+  f.s0 = (uint32_t)s0;
+  f.s1 = (uint32_t)s1;
   f.t0 = (uint8_t)t0;
   f.t1 = (uint8_t)t1;
   f.a_arr = (uint8_t)a_arr;
-  f.a_idx = (uint16_t)a_idx;
+  f.a_idx = (uint32_t)a_idx;
   f.a_neg = (uint8_t)a_neg;
-  f.slot = (uint16_t)slot;
+  f.slot = (uint32_t)slot;
   return f;
 }
 static VarTask mkvar(int s, int arr, int idx, int slot) {
   VarTask v;
-  v.s_idx = (uint16_t)s;
+  v.s_idx = (uint32_t)s;
   v.p_arr = (uint8_t)arr;
-  v.p_idx = (uint16_t)idx;
-  v.slot = (uint16_t)slot;
+  v.p_idx = (uint32_t)idx;
+  v.slot = (uint32_t)slot;
   v.neg = 0;
+  v.pad0 = v.pad1 = 0;
   return v;
 }
 static RedTask mkred(int b0, int e0, int b1, int e1, int out_arr, int out_idx) {
   RedTask r;
-  r.b0 = (uint16_t)b0;
-  r.e0 = (uint16_t)e0;
-  r.b1 = (uint16_t)b1;
-  r.e1 = (uint16_t)e1;
+  r.b0 = (uint32_t)b0;
+  r.e0 = (uint32_t)e0;
+  r.b1 = (uint32_t)b1;
+  r.e1 = (uint32_t)e1;
   r.out_arr = (uint8_t)out_arr;
-  r.out_idx = (uint16_t)out_idx;
-  r.pad = 0;
+  r.out_idx = (uint32_t)out_idx;
+  r.pad = r.pad1 = r.pad2 = 0;
   return r;
 }
 
@@ -197,13 +198,13 @@ static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& 
   for (size_t s0 = 0; s0 < terms.size(); s0 += sp.tm) {
     size_t n = terms.size() - s0 < (size_t)sp.tm ? terms.size() - s0 : (size_t)sp.tm;
     GrpTask g;
-    g.first = (uint16_t)sp.var.size();
-    g.nt = (uint16_t)n;
-    g.slot = (uint16_t)slot;
+    g.first = (uint32_t)sp.var.size();
+    g.nt = (uint32_t)n;
+    g.slot = (uint32_t)slot;
     g.pad = 0;
     for (size_t i = 0; i < n; i++) {
       VarTask v = terms[s0 + i];
-      v.slot = (uint16_t)slot;
+      v.slot = (uint32_t)slot;
       sp.var.push_back(v);
     }
     sp.grp.push_back(g);
@@ -475,10 +476,10 @@ template <class C> struct Impl {
   static void add_pair(std::vector<PairRef>& v, int p_arr, int p_idx, int neg, int q_arr, int q_idx) {
     PairRef r;
     r.p_arr = (uint8_t)p_arr;
-    r.p_idx = (uint16_t)p_idx;
+    r.p_idx = (uint32_t)p_idx;
     r.neg = (uint8_t)neg;
     r.q_arr = (uint8_t)q_arr;
-    r.q_idx = (uint16_t)q_idx;
+    r.q_idx = (uint32_t)q_idx;
     r.pad = 0;
     v.push_back(r);
   }
@@ -1089,7 +1090,7 @@ static int check_shape(gs_ctx* c, int ty, int m, int n) {
   if (ty < 0 || ty > 3) return fail(c, GS_ERR_ARG, "bad equation type");
   // the reference indexes rand[0] / gamma[0]: empty variable lists panic (prove.rs:106-113)
   if (m < 1 || n < 1) return fail(c, GS_ERR_SHAPE, "m and n must be >= 1 (reference asserts, prove.rs:106-113)");
-  if (m > 4096 || n > 4096 || (long)m * n > 60000) return fail(c, GS_ERR_SHAPE, "shape too large for task tables");
+  if (m > 4096 || n > 4096 || (long)m * n > (1L << 22)) return fail(c, GS_ERR_SHAPE, "shape too large for task tables");
   return GS_OK;
 }
 

@@ -31,24 +31,24 @@ struct OutTab {
   uint32_t stride[4];
 };
 struct VarTask {
-  uint16_t s_idx, p_idx, slot;
-  uint8_t p_arr, neg;  // neg: use -P
+  uint32_t s_idx, p_idx, slot;  // 32-bit: large-arity equations (m, n ~ 334, benches/bench.rs:451-498) have > 2^16 scalars
+  uint8_t p_arr, neg, pad0, pad1;  // neg: use -P
 };
 struct GrpTask {  // nt consecutive VarTasks summed by one lane (Straus) into one slot
-  uint16_t first, nt, slot, pad;
+  uint32_t first, nt, slot, pad;
 };
 struct FixTask {
-  uint16_t s0, s1, a_idx, slot;
+  uint32_t s0, s1, a_idx, slot;
   uint8_t t0, t1, a_arr, a_neg;  // 0xFF = absent
 };
 struct RedTask {
-  uint16_t b0, e0, b1, e1, out_idx;
-  uint8_t out_arr, pad;
+  uint32_t b0, e0, b1, e1, out_idx;
+  uint8_t out_arr, pad, pad1, pad2;
 };
 // one G2 argument with its TWO G1 partners: P(a) = parr[p_arr][p_idx + a], a = 0, 1
 struct PairRef {
   uint8_t p_arr, q_arr, neg, pad;
-  uint16_t p_idx, q_idx;
+  uint32_t p_idx, q_idx;
 };
 constexpr int MILLER_CH = 3;
 struct MillerTask {
@@ -312,14 +312,14 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var_multi(size_t total, int ngrp
   GrpTask gt = grps[g % ngrp];
   Aff<F> P[TMAX];
   Fr<C> k[TMAX];
-  for (int i = 0; i < gt.nt; i++) {
+  for (uint32_t i = 0; i < gt.nt; i++) {
     VarTask t = tasks[gt.first + i];
     k[i] = pool[e * pool_n + t.s_idx];
     aff_load<C>(P[i], arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
     if (t.neg) P[i].y = neg(P[i].y);
   }
   Jac<F> J;
-  jac_msm_straus<C, F, TMAX>(J, P, k, gt.nt);
+  jac_msm_straus<C, F, TMAX>(J, P, k, (int)gt.nt);
   part[e * nslots + gt.slot] = J;
 }
 
@@ -364,8 +364,8 @@ __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, con
   RedTask t = tasks[g % ntask];
   const Jac<F>* P = part + e * nslots;
   Jac<F> s0 = P[t.b0], s1 = P[t.b1];
-  for (int i = t.b0 + 1; i < t.e0; i++) jac_add(s0, s0, P[i]);
-  for (int i = t.b1 + 1; i < t.e1; i++) jac_add(s1, s1, P[i]);
+  for (uint32_t i = t.b0 + 1; i < t.e0; i++) jac_add(s0, s0, P[i]);
+  for (uint32_t i = t.b1 + 1; i < t.e1; i++) jac_add(s1, s1, P[i]);
   // one inversion for both components
   bool i0 = is_zero_limbs(s0.z), i1 = is_zero_limbs(s1.z);
   F z0 = i0 ? one_of<F>() : s0.z, z1 = i1 ? one_of<F>() : s1.z;

@@ -74,6 +74,12 @@ def test_ragged_shapes_ppe(shape):
     _run(0, "bls12_381", 0, 64, m, n, [0, 63])
 
 
+def test_large_arity_ppe():
+    """Towards the reference's large bench shape (benches/bench.rs:451-498, m = n = 334): a 40 x 33 PPE
+    (1320 Gamma entries, > 2^8 terms per proof element) against the C oracle, prove and verify."""
+    _run(0, "bls12_381", 0, 2, 40, 33, [1])
+
+
 def test_bn254_batch():
     _run(1, "bn254", 0, 128, 4, 4, [0, 77])
     _run(1, "bn254", 1, 64, 3, 2, [5])
