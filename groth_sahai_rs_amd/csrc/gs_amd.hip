@@ -1051,6 +1051,34 @@ int gs_set_crs(gs_ctx* c, const void* crs) {
   return DISPATCH(c, set_crs(c, crs));
 }
 
+// ---- CRS generation (generator.rs:81-118) --------------------------------------------
+int gs_crs_generate(gs_ctx* c, const void* p1, const void* p2, const void* sc, void* out) {
+  RC(check_ctx(c, false));
+  if (!p1 || !p2 || !sc || !out) return fail(c, GS_ERR_ARG, "null pointer");
+  size_t fq = sz_fq(c->curve), g1 = 2 * fq, g2 = 4 * fq;
+  const uint8_t* s = (const uint8_t*)sc;  // a1, a2, t1, t2
+  uint8_t* o = (uint8_t*)out;
+  std::vector<uint8_t> q1(g1), u1(g1), v1(g1), q2(g2), u2(g2), v2(g2);
+  // q = a*p, u = t*p, v = t*q   (prepare_real_binding_key: v = q.mul(t) - 0)
+  RC(gs_g1_mul_batch(c, 1, p1, 1, s + 0 * SZ_FR, q1.data()));
+  RC(gs_g1_mul_batch(c, 1, p1, 1, s + 2 * SZ_FR, u1.data()));
+  RC(gs_g1_mul_batch(c, 1, q1.data(), 1, s + 2 * SZ_FR, v1.data()));
+  RC(gs_g2_mul_batch(c, 1, p2, 1, s + 1 * SZ_FR, q2.data()));
+  RC(gs_g2_mul_batch(c, 1, p2, 1, s + 3 * SZ_FR, u2.data()));
+  RC(gs_g2_mul_batch(c, 1, q2.data(), 1, s + 3 * SZ_FR, v2.data()));
+  memcpy(o, p1, g1); o += g1;
+  memcpy(o, q1.data(), g1); o += g1;
+  memcpy(o, u1.data(), g1); o += g1;
+  memcpy(o, v1.data(), g1); o += g1;
+  memcpy(o, p2, g2); o += g2;
+  memcpy(o, q2.data(), g2); o += g2;
+  memcpy(o, u2.data(), g2); o += g2;
+  memcpy(o, v2.data(), g2); o += g2;
+  memcpy(o, p1, g1); o += g1;
+  memcpy(o, p2, g2); o += g2;
+  return gs_multi_pairing_batch(c, 1, 1, p1, p2, o);
+}
+
 // ---- commit ------------------------------------------------------------------
 #define COMMIT_DEV(NAME, FT, GROUP, TAB, TAG)                                                              \
   int NAME(gs_ctx* c, size_t n, const void* v, const void* r, void* out) {                                 \

@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's operator interface for the hot path, on
 top of the C ABI (same names, argument meaning and error behaviour):
 
-    CRS                                   src/generator.rs:35-42 (struct only; generation is out of scope)
+    CRS, generate_crs                     src/generator.rs:35-42, 81-118 (generators supplied by the caller)
     Commit1 / Commit2 {coms, rand}        src/prover/commit.rs:18-28
     batch_commit_G1 / _G2 / _scalar_to_B1 / _scalar_to_B2, commit_G1 ...   commit.rs:59-256
     PPE / MSMEG1 / MSMEG2 / QuadEqu {a_consts, b_consts, gamma, target}     src/statement.rs:117-192
@@ -36,6 +36,23 @@ class CRS:
         flat = np.concatenate([np.asarray(x, dtype=np.uint64).reshape(-1) for x in (u[0], u[1], v[0], v[1], g1_gen,
                                                                                    g2_gen, gt_gen)])
         self.engine.set_crs(flat)
+
+
+def generate_crs(p1, p2, rng, curve=0, device=0):
+    """AbstractCrs::generate_crs (generator.rs:81-118) with the group generators supplied by the caller
+    (the reference draws them with G1::rand / G2::rand, which has no counterpart outside arkworks);
+    the four scalars a1, a2, t1, t2 are drawn from `rng` in the reference's order (generator.rs:90-93)."""
+    eng = Engine(curve, device)
+    sc = np.concatenate([rng.fr() for _ in range(4)])
+    raw = eng.crs_generate(p1, p2, sc).view(np.uint64)
+    eng.close()
+    g1, g2 = eng.G1 // 8, eng.G2 // 8
+    o = 0
+    parts = []
+    for sz in (2 * g1, 2 * g1, 2 * g2, 2 * g2, g1, g2, eng.GT // 8):
+        parts.append(raw[o:o + sz].copy())
+        o += sz
+    return CRS([parts[0], parts[1]], [parts[2], parts[3]], parts[4], parts[5], parts[6], curve, device)
 
 
 class Commit1:

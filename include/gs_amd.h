@@ -73,6 +73,12 @@ int gs_sizes(int curve_id, size_t out[6]);
  * builds the windowed fixed-base tables on the device. */
 int gs_set_crs(gs_ctx* ctx, const void* crs_host);
 
+/* CRS of the reference's shape (src/generator.rs:81-118, binding key :48-60) from caller-drawn values:
+ * generators p1 (G1), p2 (G2) and scalars[4] = a1, a2, t1, t2 (Fr):
+ *   u = [(p1, a1 p1), (t1 p1, t1 a1 p1)],  v = [(p2, a2 p2), (t2 p2, t2 a2 p2)],  g1 = p1, g2 = p2, gt = e(p1, p2).
+ * Host pointers; the result is written to crs_out (CRS layout) and NOT installed (call gs_set_crs). */
+int gs_crs_generate(gs_ctx* ctx, const void* p1_g1, const void* p2_g2, const void* scalars_fr4, void* crs_out);
+
 /* ---- commit (src/prover/commit.rs) -------------------------------------- */
 /* c_i = iota1(X_i) + r_i0 u0 + r_i1 u1   (commit.rs:78-100; N=1 is commit_G1 :59-75) */
 int gs_commit_g1_dev(gs_ctx*, size_t count, const void* x_g1, const void* rand_fr2, void* out_com1);
