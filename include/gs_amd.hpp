@@ -1,0 +1,293 @@
+// gs_amd.hpp -- C++17 host-side mirror of the reference's operator interface for the
+// hot path, header-only on top of the C ABI (gs_amd.h).  Same names, argument
+// meaning and error behaviour as the Rust API it stands in for (the reference's
+// toolchain is absent from the build image, so the host layer a Rust shim would
+// provide is written in C++; INTEGRATION.md shows the Rust-side binding):
+//
+//   CRS, CRS::generate_crs                       src/generator.rs:35-42, 81-118
+//   Commit1 / Commit2 {coms, rand}, append        src/prover/commit.rs:18-56
+//   commit_G1 / batch_commit_G1 / ..._scalar_to_B2 src/prover/commit.rs:59-256
+//   EquType                                       src/statement.rs:42-49
+//   PPE / MSMEG1 / MSMEG2 / QuadEqu               src/statement.rs:117-192
+//     .commit_and_prove(xvars, yvars, crs, rng)   src/prover/prove.rs:29-52 (Provable)
+//     .prove(xvars, yvars, xcoms, ycoms, crs, rng)
+//     .verify(com_proof, crs) -> bool             src/verifier.rs:18-21   (Verifiable)
+//   EquProof {pi, theta, equ_type, rand}, CProof  src/prover/prove.rs:55-69
+//
+// Values are byte strings in the boundary layout of gs_amd.h (arkworks' Montgomery
+// limbs).  `Rng` is any type with `Fr fr()`; draws happen in the reference's order
+// (R row-major, then S, then T).  Where the reference panics (assert_eq!,
+// prove.rs:106-113, verifier.rs:25-26) these functions throw gs_amd::Panic.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gs_amd.h"
+
+namespace gs_amd {
+
+struct Panic : std::logic_error {
+  using std::logic_error::logic_error;
+};
+inline void assert_eq(size_t a, size_t b, const char* what) {
+  if (a != b) throw Panic(std::string("assertion failed: ") + what);
+}
+
+using Bytes = std::vector<uint8_t>;
+struct Fr { Bytes v; };
+struct G1Affine { Bytes v; };
+struct G2Affine { Bytes v; };
+struct GT { Bytes v; };  // PairingOutput
+struct Com1 { Bytes v; };  // G1 || G1
+struct Com2 { Bytes v; };  // G2 || G2
+template <class T> using Matrix = std::vector<std::vector<T>>;
+inline bool operator==(const Fr& a, const Fr& b) { return a.v == b.v; }
+inline bool operator==(const Com1& a, const Com1& b) { return a.v == b.v; }
+inline bool operator==(const Com2& a, const Com2& b) { return a.v == b.v; }
+
+enum class EquType : uint8_t { PairingProduct = 0, MultiScalarG1 = 1, MultiScalarG2 = 2, Quadratic = 3 };
+
+// one GPU context per CRS (gs_ctx_create + gs_set_crs), shared by copies of the CRS
+struct Ctx {
+  gs_ctx* c = nullptr;
+  size_t sz[6] = {0, 0, 0, 0, 0, 0};  // Fq, Fr, G1, G2, GT, CRS
+  Ctx(int curve, int device) {
+    if (gs_sizes(curve, sz) != GS_OK) throw std::runtime_error("bad curve id");
+    int rc = gs_ctx_create(curve, device, &c);
+    if (rc != GS_OK) throw std::runtime_error("gs_ctx_create failed (no usable GPU; there is no CPU fallback)");
+  }
+  ~Ctx() { gs_ctx_destroy(c); }
+  void chk(int rc) const {
+    if (rc == GS_ERR_SHAPE) throw Panic(gs_last_error(c));
+    if (rc != GS_OK) throw std::runtime_error(std::string("gs_amd error: ") + gs_last_error(c));
+  }
+};
+
+template <class T> inline Bytes cat(const std::vector<T>& xs) {
+  Bytes o;
+  for (const T& x : xs) o.insert(o.end(), x.v.begin(), x.v.end());
+  return o;
+}
+inline Bytes cat(const Matrix<Fr>& m) {
+  Bytes o;
+  for (const auto& row : m)
+    for (const Fr& x : row) o.insert(o.end(), x.v.begin(), x.v.end());
+  return o;
+}
+template <class T> inline std::vector<T> split(const Bytes& b, size_t n) {
+  std::vector<T> o(n);
+  size_t w = n ? b.size() / n : 0;
+  for (size_t i = 0; i < n; i++) o[i].v.assign(b.begin() + i * w, b.begin() + (i + 1) * w);
+  return o;
+}
+
+struct CRS {  // generator.rs:35-42
+  std::vector<Com1> u;
+  std::vector<Com2> v;
+  G1Affine g1_gen;
+  G2Affine g2_gen;
+  GT gt_gen;
+  std::shared_ptr<Ctx> ctx;
+
+  CRS(std::vector<Com1> u_, std::vector<Com2> v_, G1Affine g1, G2Affine g2, GT gt, int curve = GS_CURVE_BLS12_381,
+      int device = 0)
+      : u(std::move(u_)), v(std::move(v_)), g1_gen(std::move(g1)), g2_gen(std::move(g2)), gt_gen(std::move(gt)),
+        ctx(std::make_shared<Ctx>(curve, device)) {
+    Bytes flat = cat(u);
+    Bytes t = cat(v);
+    flat.insert(flat.end(), t.begin(), t.end());
+    flat.insert(flat.end(), g1_gen.v.begin(), g1_gen.v.end());
+    flat.insert(flat.end(), g2_gen.v.begin(), g2_gen.v.end());
+    flat.insert(flat.end(), gt_gen.v.begin(), gt_gen.v.end());
+    assert_eq(flat.size(), ctx->sz[5], "CRS size");
+    ctx->chk(gs_set_crs(ctx->c, flat.data()));
+  }
+  // AbstractCrs::generate_crs (generator.rs:81-118); the generators come from the caller, the
+  // scalars a1, a2, t1, t2 from the rng in the reference's order (:90-93)
+  template <class Rng>
+  static CRS generate_crs(const G1Affine& p1, const G2Affine& p2, Rng& rng, int curve = GS_CURVE_BLS12_381,
+                          int device = 0) {
+    Ctx tmp(curve, device);
+    Bytes sc;
+    for (int i = 0; i < 4; i++) {
+      Fr s = rng.fr();
+      sc.insert(sc.end(), s.v.begin(), s.v.end());
+    }
+    Bytes raw(tmp.sz[5]);
+    tmp.chk(gs_crs_generate(tmp.c, p1.v.data(), p2.v.data(), sc.data(), raw.data()));
+    size_t g1 = tmp.sz[2], g2 = tmp.sz[3], o = 0;
+    auto take = [&](size_t n) {
+      Bytes b(raw.begin() + o, raw.begin() + o + n);
+      o += n;
+      return b;
+    };
+    std::vector<Com1> u{{take(2 * g1)}, {take(2 * g1)}};
+    std::vector<Com2> v{{take(2 * g2)}, {take(2 * g2)}};
+    G1Affine a{take(g1)};
+    G2Affine b{take(g2)};
+    GT t{take(tmp.sz[4])};
+    return CRS(u, v, a, b, t, curve, device);
+  }
+};
+
+template <class C> struct CommitT {  // commit.rs:18-28
+  std::vector<C> coms;
+  Matrix<Fr> rand;
+  bool operator==(const CommitT& o) const {
+    if (coms.size() != o.coms.size() || rand.size() != o.rand.size()) return false;
+    for (size_t i = 0; i < coms.size(); i++)
+      if (!(coms[i] == o.coms[i])) return false;
+    for (size_t i = 0; i < rand.size(); i++) {
+      if (rand[i].size() != o.rand[i].size()) return false;
+      for (size_t j = 0; j < rand[i].size(); j++)
+        if (!(rand[i][j] == o.rand[i][j])) return false;
+    }
+    return true;
+  }
+  void append(CommitT& other) {  // commit.rs:43-51
+    assert_eq(coms.size(), rand.size(), "self.coms.len() == self.rand.len()");
+    assert_eq(other.coms.size(), other.rand.size(), "other.coms.len() == other.rand.len()");
+    coms.insert(coms.end(), other.coms.begin(), other.coms.end());
+    rand.insert(rand.end(), other.rand.begin(), other.rand.end());
+    other.coms.clear();
+    other.rand.clear();
+  }
+};
+using Commit1 = CommitT<Com1>;
+using Commit2 = CommitT<Com2>;
+
+namespace detail {
+template <class Rng> Matrix<Fr> draw(Rng& rng, size_t rows, size_t cols) {
+  Matrix<Fr> m(rows);
+  for (auto& r : m)
+    for (size_t j = 0; j < cols; j++) r.push_back(rng.fr());
+  return m;
+}
+template <class Com, class V, class Rng, class F>
+CommitT<Com> batch_commit(const std::vector<V>& vars, const CRS& key, Rng& rng, size_t cols, size_t out_sz, F fn) {
+  CommitT<Com> c;
+  c.rand = draw(rng, vars.size(), cols);
+  if (vars.empty()) return c;
+  Bytes in = cat(vars), r = cat(c.rand), out(vars.size() * out_sz);
+  key.ctx->chk(fn(key.ctx->c, vars.size(), in.data(), r.data(), out.data()));
+  c.coms = split<Com>(out, vars.size());
+  return c;
+}
+}  // namespace detail
+
+// commit.rs:78-100, 178-200, 125-156, 225-256 (+ the single-element forms :59-75, 103-122, 159-175, 203-222)
+template <class Rng> Commit1 batch_commit_G1(const std::vector<G1Affine>& xvars, const CRS& key, Rng& rng) {
+  return detail::batch_commit<Com1>(xvars, key, rng, 2, 2 * key.ctx->sz[2], gs_commit_g1);
+}
+template <class Rng> Commit2 batch_commit_G2(const std::vector<G2Affine>& yvars, const CRS& key, Rng& rng) {
+  return detail::batch_commit<Com2>(yvars, key, rng, 2, 2 * key.ctx->sz[3], gs_commit_g2);
+}
+template <class Rng> Commit1 batch_commit_scalar_to_B1(const std::vector<Fr>& xs, const CRS& key, Rng& rng) {
+  return detail::batch_commit<Com1>(xs, key, rng, 1, 2 * key.ctx->sz[2], gs_commit_fr_b1);
+}
+template <class Rng> Commit2 batch_commit_scalar_to_B2(const std::vector<Fr>& ys, const CRS& key, Rng& rng) {
+  return detail::batch_commit<Com2>(ys, key, rng, 1, 2 * key.ctx->sz[3], gs_commit_fr_b2);
+}
+template <class Rng> Commit1 commit_G1(const G1Affine& x, const CRS& key, Rng& rng) {
+  return batch_commit_G1(std::vector<G1Affine>{x}, key, rng);
+}
+template <class Rng> Commit2 commit_G2(const G2Affine& y, const CRS& key, Rng& rng) {
+  return batch_commit_G2(std::vector<G2Affine>{y}, key, rng);
+}
+template <class Rng> Commit1 commit_scalar_to_B1(const Fr& x, const CRS& key, Rng& rng) {
+  return batch_commit_scalar_to_B1(std::vector<Fr>{x}, key, rng);
+}
+template <class Rng> Commit2 commit_scalar_to_B2(const Fr& y, const CRS& key, Rng& rng) {
+  return batch_commit_scalar_to_B2(std::vector<Fr>{y}, key, rng);
+}
+// overload selection by witness type (used by commit_and_prove)
+template <class Rng> Commit1 batch_commit_x(const std::vector<G1Affine>& x, const CRS& k, Rng& r) { return batch_commit_G1(x, k, r); }
+template <class Rng> Commit1 batch_commit_x(const std::vector<Fr>& x, const CRS& k, Rng& r) { return batch_commit_scalar_to_B1(x, k, r); }
+template <class Rng> Commit2 batch_commit_y(const std::vector<G2Affine>& y, const CRS& k, Rng& r) { return batch_commit_G2(y, k, r); }
+template <class Rng> Commit2 batch_commit_y(const std::vector<Fr>& y, const CRS& k, Rng& r) { return batch_commit_scalar_to_B2(y, k, r); }
+
+struct EquProof {  // prove.rs:55-61
+  std::vector<Com2> pi;
+  std::vector<Com1> theta;
+  EquType equ_type;
+  Matrix<Fr> rand;
+};
+struct CProof {  // prove.rs:64-69
+  Commit1 xcoms;
+  Commit2 ycoms;
+  std::vector<EquProof> equ_proofs;
+};
+
+template <class T> struct is_scalar { static constexpr bool value = false; };
+template <> struct is_scalar<Fr> { static constexpr bool value = true; };
+
+// statement.rs:117-192: a_consts pair with the Y variables and live in A1, b_consts in A2
+template <class A1, class A2, class AT, EquType TYPE> struct Equation {
+  std::vector<A1> a_consts;
+  std::vector<A2> b_consts;
+  Matrix<Fr> gamma;
+  AT target;
+  static constexpr size_t KX = is_scalar<A1>::value ? 1 : 2;  // columns of R = number of pi elements
+  static constexpr size_t KY = is_scalar<A2>::value ? 1 : 2;  // columns of S = number of theta elements
+
+  EquType get_type() const { return TYPE; }
+
+  template <class Rng>
+  CProof commit_and_prove(const std::vector<A1>& xvars, const std::vector<A2>& yvars, const CRS& crs, Rng& rng) const {
+    Commit1 xcoms = batch_commit_x(xvars, crs, rng);
+    Commit2 ycoms = batch_commit_y(yvars, crs, rng);
+    CProof p{xcoms, ycoms, {}};
+    p.equ_proofs.push_back(prove(xvars, yvars, xcoms, ycoms, crs, rng));
+    return p;
+  }
+
+  template <class Rng>
+  EquProof prove(const std::vector<A1>& xvars, const std::vector<A2>& yvars, const Commit1& xcoms,
+                 const Commit2& ycoms, const CRS& crs, Rng& rng) const {
+    // the reference's shape asserts (prove.rs:106-113); empty lists panic there on rand[0]
+    assert_eq(xvars.size(), xcoms.rand.size(), "xvars.len() == xcoms.rand.len()");
+    assert_eq(gamma.size(), xcoms.rand.size(), "gamma.len() == xcoms.rand.len()");
+    if (xcoms.rand.empty() || ycoms.rand.empty() || gamma.empty()) throw Panic("index out of bounds: rand[0]");
+    assert_eq(xcoms.rand[0].size(), KX, "xcoms.rand[0].len()");
+    assert_eq(yvars.size(), ycoms.rand.size(), "yvars.len() == ycoms.rand.len()");
+    assert_eq(gamma[0].size(), ycoms.rand.size(), "gamma[0].len() == ycoms.rand.len()");
+    assert_eq(ycoms.rand[0].size(), KY, "ycoms.rand[0].len()");
+    size_t m = xvars.size(), n = yvars.size();
+    Matrix<Fr> T = detail::draw(rng, KY, KX);
+    Bytes X = cat(xvars), Y = cat(yvars), A = cat(a_consts), B = cat(b_consts), G = cat(gamma), R = cat(xcoms.rand),
+          S = cat(ycoms.rand), Tb = cat(T);
+    const Ctx& cx = *crs.ctx;
+    Bytes pi(KX * 2 * cx.sz[3]), th(KY * 2 * cx.sz[2]);
+    cx.chk(gs_prove_batch(cx.c, (int)TYPE, 1, (int)m, (int)n, X.data(), Y.data(), A.data(), B.data(), G.data(),
+                          R.data(), S.data(), Tb.data(), nullptr, nullptr, pi.data(), th.data()));
+    EquProof pf{split<Com2>(pi, KX), split<Com1>(th, KY), TYPE, T};
+    assert_eq(pf.pi.size(), KX, "pi.len()");
+    assert_eq(pf.theta.size(), KY, "theta.len()");
+    return pf;
+  }
+
+  bool verify(const CProof& com_proof, const CRS& crs) const {  // verifier.rs:23-157
+    assert_eq(com_proof.equ_proofs.size(), 1, "com_proof.equ_proofs.len() == 1");
+    if (com_proof.equ_proofs[0].equ_type != TYPE) throw Panic("assertion failed: equation type matches the proof's");
+    const EquProof& pf = com_proof.equ_proofs[0];
+    size_t m = com_proof.xcoms.coms.size(), n = com_proof.ycoms.coms.size();
+    Bytes A = cat(a_consts), B = cat(b_consts), G = cat(gamma), xc = cat(com_proof.xcoms.coms),
+          yc = cat(com_proof.ycoms.coms), pi = cat(pf.pi), th = cat(pf.theta);
+    uint8_t ok = 0;
+    const Ctx& cx = *crs.ctx;
+    cx.chk(gs_verify_batch(cx.c, (int)TYPE, 1, (int)m, (int)n, A.data(), B.data(), G.data(), target.v.data(),
+                           xc.data(), yc.data(), pi.data(), th.data(), &ok));
+    return ok == 1;
+  }
+};
+
+using PPE = Equation<G1Affine, G2Affine, GT, EquType::PairingProduct>;
+using MSMEG1 = Equation<G1Affine, Fr, G1Affine, EquType::MultiScalarG1>;
+using MSMEG2 = Equation<Fr, G2Affine, G2Affine, EquType::MultiScalarG2>;
+using QuadEqu = Equation<Fr, Fr, Fr, EquType::Quadratic>;
+
+}  // namespace gs_amd

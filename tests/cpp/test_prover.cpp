@@ -1,0 +1,173 @@
+// The reference's integration tests (tests/prover.rs:25-172; prove.rs:510-589; commit.rs:440-548)
+// restated in C++ against include/gs_amd.hpp, run on the GPU through the C ABI.
+// Input: a case blob written by tests/test_gpu_cpp_host.py from tests/golden/*.json:
+//   u32 curve, type, m, n; then length-prefixed (u64) sections
+//   u0 u1 v0 v1 g1 g2 gt X Y A B Gamma target R S T xcoms ycoms pi theta
+// Exit code 0 and "OK <checks>" on success.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "gs_amd.hpp"
+
+using namespace gs_amd;
+
+static int checks = 0;
+#define CHECK(c)                                                   \
+  do {                                                             \
+    if (!(c)) {                                                    \
+      std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, #c); \
+      std::exit(1);                                                \
+    }                                                              \
+    checks++;                                                      \
+  } while (0)
+
+struct ReplayRng {  // stands in for `&mut CR: Rng`: hands out the recorded draws in order
+  std::vector<Fr> q;
+  size_t i = 0;
+  Fr fr() {
+    if (i >= q.size()) {
+      std::fprintf(stderr, "rng exhausted\n");
+      std::exit(1);
+    }
+    return q[i++];
+  }
+};
+
+static Bytes section(std::ifstream& f) {
+  uint64_t n = 0;
+  f.read((char*)&n, 8);
+  Bytes b(n);
+  f.read((char*)b.data(), n);
+  if (!f) {
+    std::fprintf(stderr, "short case file\n");
+    std::exit(2);
+  }
+  return b;
+}
+
+template <class A1, class A2, class AT, EquType TY>
+static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const Bytes& Y, const Bytes& A, const Bytes& B,
+                const Bytes& G, const Bytes& tgt, const Bytes& R, const Bytes& S, const Bytes& T, const Bytes& xc,
+                const Bytes& yc, const Bytes& pi, const Bytes& th) {
+  using Equ = Equation<A1, A2, AT, TY>;
+  size_t fr = crs.ctx->sz[1];
+  Equ equ;
+  equ.a_consts = split<A1>(A, n);
+  equ.b_consts = split<A2>(B, m);
+  auto gflat = split<Fr>(G, (size_t)m * n);
+  equ.gamma.resize(m);
+  for (uint32_t i = 0; i < m; i++) equ.gamma[i].assign(gflat.begin() + i * n, gflat.begin() + (i + 1) * n);
+  equ.target.v = tgt;
+  auto xvars = split<A1>(X, m);
+  auto yvars = split<A2>(Y, n);
+  auto rng_of = [&](std::initializer_list<const Bytes*> parts) {
+    ReplayRng r;
+    for (const Bytes* p : parts) {
+      auto v = split<Fr>(*p, p->size() / fr);
+      r.q.insert(r.q.end(), v.begin(), v.end());
+    }
+    return r;
+  };
+
+  // tests/prover.rs: verify(commit_and_prove(..)) and bit-exact outputs for the recorded draws
+  ReplayRng rng = rng_of({&R, &S, &T});
+  CProof proof = equ.commit_and_prove(xvars, yvars, crs, rng);
+  CHECK(rng.i == rng.q.size());  // draw order R, S, T and nothing else
+  CHECK(proof.equ_proofs.size() == 1);
+  CHECK(proof.equ_proofs[0].equ_type == TY && equ.get_type() == TY);  // prove.rs:510-536
+  CHECK(proof.equ_proofs[0].pi.size() == Equ::KX && proof.equ_proofs[0].theta.size() == Equ::KY);
+  CHECK(cat(proof.xcoms.coms) == xc);
+  CHECK(cat(proof.ycoms.coms) == yc);
+  CHECK(cat(proof.equ_proofs[0].pi) == pi);
+  CHECK(cat(proof.equ_proofs[0].theta) == th);
+  CHECK(cat(proof.xcoms.rand) == R && cat(proof.ycoms.rand) == S && cat(proof.equ_proofs[0].rand) == T);
+  CHECK(equ.verify(proof, crs));
+
+  // prove.rs:538-589: commit_and_prove == batch commits + prove under re-synchronised RNGs
+  ReplayRng rng2 = rng_of({&R, &S, &T});
+  Commit1 xcoms = batch_commit_x(xvars, crs, rng2);
+  Commit2 ycoms = batch_commit_y(yvars, crs, rng2);
+  CHECK(xcoms == proof.xcoms && ycoms == proof.ycoms);
+  EquProof pf = equ.prove(xvars, yvars, xcoms, ycoms, crs, rng2);
+  CHECK(cat(pf.pi) == pi && cat(pf.theta) == th);
+
+  // commit.rs:440-548: batch commit == sequence of single commits under a synchronised RNG
+  {
+    ReplayRng r1 = rng_of({&R});
+    Commit1 acc;
+    for (const auto& x : xvars) {
+      Commit1 one = batch_commit_x(std::vector<A1>{x}, crs, r1);
+      acc.append(one);
+      CHECK(one.coms.empty() && one.rand.empty());
+    }
+    CHECK(acc == xcoms);
+    ReplayRng r2 = rng_of({&S});
+    Commit2 acc2;
+    for (const auto& y : yvars) {
+      Commit2 one = batch_commit_y(std::vector<A2>{y}, crs, r2);
+      acc2.append(one);
+    }
+    CHECK(acc2 == ycoms);
+  }
+
+  // negatives: a tampered proof element, commitment and target must be rejected
+  {
+    CProof bad = proof;
+    bad.equ_proofs[0].pi[0] = bad.equ_proofs[0].pi[Equ::KX - 1 ? 1 : 0];
+    if (Equ::KX > 1) CHECK(!equ.verify(bad, crs));
+    bad = proof;
+    std::swap(bad.xcoms.coms[0], bad.xcoms.coms[m - 1]);
+    if (m > 1 && !(proof.xcoms.coms[0] == proof.xcoms.coms[m - 1])) CHECK(!equ.verify(bad, crs));
+    Equ other = equ;
+    other.gamma[0][0] = gflat[0].v == Bytes(fr, 0) ? rng_of({&R}).fr() : Fr{Bytes(fr, 0)};
+    CHECK(!other.verify(proof, crs));
+  }
+
+  // shape asserts panic (prove.rs:106-113; verifier.rs:25-26)
+  {
+    bool threw = false;
+    try {
+      std::vector<A1> shortx(xvars.begin(), xvars.end() - 1);
+      ReplayRng r = rng_of({&T});
+      equ.prove(shortx, yvars, xcoms, ycoms, crs, r);
+    } catch (const Panic&) {
+      threw = true;
+    }
+    CHECK(threw);
+    threw = false;
+    try {
+      CProof two = proof;
+      two.equ_proofs.push_back(two.equ_proofs[0]);
+      equ.verify(two, crs);
+    } catch (const Panic&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::fprintf(stderr, "usage: %s case.bin\n", argv[0]);
+    return 2;
+  }
+  std::ifstream f(argv[1], std::ios::binary);
+  uint32_t hdr[4];
+  f.read((char*)hdr, 16);
+  Bytes s[20];
+  for (auto& b : s) b = section(f);
+  CRS crs({Com1{s[0]}, Com1{s[1]}}, {Com2{s[2]}, Com2{s[3]}}, G1Affine{s[4]}, G2Affine{s[5]}, GT{s[6]}, (int)hdr[0]);
+  uint32_t ty = hdr[1], m = hdr[2], n = hdr[3];
+#define ARGS crs, m, n, s[7], s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15], s[16], s[17], s[18], s[19]
+  switch (ty) {
+    case 0: run<G1Affine, G2Affine, GT, EquType::PairingProduct>(ARGS); break;
+    case 1: run<G1Affine, Fr, G1Affine, EquType::MultiScalarG1>(ARGS); break;
+    case 2: run<Fr, G2Affine, G2Affine, EquType::MultiScalarG2>(ARGS); break;
+    case 3: run<Fr, Fr, Fr, EquType::Quadratic>(ARGS); break;
+    default: return 2;
+  }
+  std::printf("OK %d\n", checks);
+  return 0;
+}
