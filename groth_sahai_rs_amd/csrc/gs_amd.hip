@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -51,6 +52,9 @@ struct gs_ctx {
   std::map<std::string, ProfEntry> prof_map;
   std::vector<std::string> prof_order;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // SIMD slots of the device (CUs x 4); every heavy kernel runs one 512-VGPR wave per SIMD
+  size_t simd_slots = 1024;
+  int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
 };
 
 static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -660,8 +664,14 @@ template <class C> struct Impl {
     int ntask = (int)vp.mt.size();
     void* cellok;
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
-    RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cm,
-              (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
+    // one lane per final exponentiation once that fills the chip, 3-lane groups (21 per wave) below that
+    size_t coop_waves = (N * 4 + 20) / 21;
+    if (c->coop_fe == 2 || (c->coop_fe == 1 && coop_waves <= c->simd_slots))
+      RC(launch(c, "k_final.coop", k_final_coop<C>, coop_waves * 63, 63, N, ntask, vp.cm, (const GT*)mpart,
+                ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
+    else
+      RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cm,
+                (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
     RC(launch(c, "k_and4", k_and4, N, 64, N, (const uint8_t*)cellok, ok));
     return GS_OK;
   }
@@ -882,7 +892,7 @@ template <class C> struct Impl {
     RC(gt_product(c, count, (GT*)d, (GT*)t, (uint8_t*)twob));
     RC(gt_product(c, count, (GT*)d + count, (GT*)t, (uint8_t*)twob + Z::GT));
     RC(launch(c, "k_gt_import", k_gt_import<C>, 2, 64, (size_t)2, (const uint8_t*)twob, (GT*)two));
-    RC(launch(c, "k_fe_eq", k_fe_eq<C>, 1, 64, (const GT*)two, (uint8_t*)dok));
+    RC(launch(c, "k_fe_eq", k_fe_eq<C>, 3, 3, (const GT*)two, (uint8_t*)dok));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(ok_host, dok, 1, hipMemcpyDeviceToHost));
     return GS_OK;
@@ -1012,6 +1022,10 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
   gs_ctx* c = new gs_ctx();
   c->curve = curve;
   c->device = device;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+    c->simd_slots = 4 * (size_t)cus;
+  if (const char* e = getenv("GS_COOP_FE")) c->coop_fe = atoi(e);
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return GS_ERR_DEVICE;

@@ -15,6 +15,7 @@
 //              compare (verifier.rs:50-53)
 #pragma once
 #include "gs_pairing.cuh"
+#include "gs_coop.cuh"
 
 namespace gs {
 
@@ -454,6 +455,35 @@ __global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, CellM
   cellok[g] = ok ? 1 : 0;
 }
 
+// The same with a 3-lane group per cell (gs_coop.cuh) for batches that cannot fill the chip with one lane per
+// final exponentiation.  blockDim.x == 63: one wave = 21 groups; idle groups of the last wave shadow the last cell so
+// that every lane reaches the shuffles.
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE) k_final_coop(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart,
+                                                   const uint8_t* target, uint8_t* cellok) {
+  int lane = (int)threadIdx.x, j = lane % 3;
+  size_t g = (size_t)blockIdx.x * 21 + lane / 3;
+  bool live = g < N * 4;
+  if (!live) g = N * 4 - 1;
+  size_t e = g >> 2;
+  int c = (int)(g & 3);
+  Fp12<C> f;
+  cell_product(f, mpart, e, ntask, c, cm);
+  Fp12<C> r;
+  CoopWave xw{lane - j};
+  ExpXCoop<C, CoopWave> ex{j, &xw};
+  final_exp_with(r, f, ex);
+  bool ok;
+  if (c == 3 && target) {
+    Fp12<C> t;
+    f12_from_boundary<C>(t, reinterpret_cast<const BFq<C>*>(target) + 12 * e);
+    ok = f12_eq(r, t);
+  } else {
+    ok = f12_is_one(r);
+  }
+  if (live && j == 0) cellok[g] = ok ? 1 : 0;
+}
+
 __global__ void k_and4(size_t N, const uint8_t* cellok, uint8_t* ok) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
@@ -543,11 +573,15 @@ template <class C> __global__ void __launch_bounds__(64, GS_WPE) k_gt_import(siz
   out[g] = t;
 }
 // acc[0] = Miller-side accumulator, acc[1] = target-side accumulator: ok = (FE(acc[0]) == acc[1])
+// launched with ONE block of 3 lanes: a single 3-lane cooperative final exponentiation
 template <class C> __global__ void k_fe_eq(const Fp12<C>* acc, uint8_t* ok) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int j = (int)threadIdx.x;
   Fp12<C> r;
-  final_exp(r, acc[0]);
-  ok[0] = f12_eq(r, acc[1]) ? 1 : 0;
+  CoopWave xw{0};
+  ExpXCoop<C, CoopWave> ex{j, &xw};
+  final_exp_with(r, acc[0], ex);
+  bool same = f12_eq(r, acc[1]);
+  if (j == 0) ok[0] = same ? 1 : 0;
 }
 template <class C> __global__ void k_gt_set_one(Fp12<C>* p) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;

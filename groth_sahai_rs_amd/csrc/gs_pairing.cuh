@@ -230,8 +230,12 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f
   r = acc;
 }
 
-// Final exponentiation, arkworks' exponent.  Returns false if f = 0.
-template <class C> GS_HD_NOINLINE void final_exp(Fp12<C>& out, const Fp12<C>& f) {
+// Final exponentiation, arkworks' exponent.  `ex(r, f)` computes r = f^x: one lane
+// (f12_exp_by_x) or a 3-lane group (gs_coop.cuh).
+template <class C> struct ExpXLane {
+  GS_HD void operator()(Fp12<C>& r, const Fp12<C>& f) const { f12_exp_by_x(r, f); }
+};
+template <class C, class EX> GS_HD_NOINLINE void final_exp_with(Fp12<C>& out, const Fp12<C>& f, EX& ex) {
   Fp12<C> r, t, y0, y1, y2;
   // easy part: f^((p^6-1)(p^2+1))
   f12_inv(t, f);
@@ -243,18 +247,18 @@ template <class C> GS_HD_NOINLINE void final_exp(Fp12<C>& out, const Fp12<C>& f)
     // hard part, eprint 2020/875 (Hayashida-Hayasaka-Teruya): exponent
     // (x-1)^2 (x+p) (x^2+p^2-1) + 3
     f12_cyclo_sqr(y0, r);       // r^2
-    f12_exp_by_x(y1, r);        // r^x
+    ex(y1, r);        // r^x
     f12_conj(y2, r);            // r^-1
     f12_mul(y1, y1, y2);        // r^(x-1)
-    f12_exp_by_x(y2, y1);       // r^(x(x-1))
+    ex(y2, y1);       // r^(x(x-1))
     f12_conj(y1, y1);           // r^-(x-1)
     f12_mul(y1, y1, y2);        // r^((x-1)^2)
-    f12_exp_by_x(y2, y1);       // ^x
+    ex(y2, y1);       // ^x
     f12_frob(y1, y1, 1);        // ^p
     f12_mul(y1, y1, y2);        // r^((x-1)^2 (x+p))
     f12_mul(r, r, y0);          // r^3
-    f12_exp_by_x(y0, y1);       // ^x
-    f12_exp_by_x(y2, y0);       // ^x^2
+    ex(y0, y1);       // ^x
+    ex(y2, y0);       // ^x^2
     f12_frob(y0, y1, 2);        // ^p^2
     f12_conj(y1, y1);           // ^-1
     f12_mul(y1, y1, y2);
@@ -264,15 +268,15 @@ template <class C> GS_HD_NOINLINE void final_exp(Fp12<C>& out, const Fp12<C>& f)
     // BN hard part (Fuentes-Castaneda et al.), as ark-ec models::bn [ark-mem].
     // exp_by_neg_x(f) = f^(-x)
     Fp12<C> y3, y4, y5, y6, y7, y8, y9;
-    f12_exp_by_x(y0, r);
+    ex(y0, r);
     f12_conj(y0, y0);           // r^-x
     f12_cyclo_sqr(y1, y0);
     f12_cyclo_sqr(y2, y1);
     f12_mul(y3, y2, y1);
-    f12_exp_by_x(y4, y3);
+    ex(y4, y3);
     f12_conj(y4, y4);
     f12_cyclo_sqr(y5, y4);
-    f12_exp_by_x(y6, y5);
+    ex(y6, y5);
     f12_conj(y6, y6);
     f12_conj(y3, y3);
     f12_conj(y6, y6);
@@ -290,6 +294,10 @@ template <class C> GS_HD_NOINLINE void final_exp(Fp12<C>& out, const Fp12<C>& f)
     f12_frob(y9, y9, 3);
     f12_mul(out, y9, y2);       // y16
   }
+}
+template <class C> GS_HD void final_exp(Fp12<C>& out, const Fp12<C>& f) {
+  ExpXLane<C> ex;
+  final_exp_with(out, f, ex);
 }
 
 }  // namespace gs

@@ -168,3 +168,28 @@ def test_straus_msm_equals_left_mul_fixture(twin, cname):
             out2 = np.zeros(4 * c.nq, dtype=np.uint64)
             getattr(twin, "twin_g2_msm_" + cname)(k, ptr(P2), ptr(ks), ptr(out2))
             assert c.g2_dec(out2) == lm["out2"][i][comp]
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_cooperative_final_exponentiation(twin, cname):
+    """gs_coop.cuh: the 3-lane f^x and the final exponentiation built on it give, on every lane, exactly the
+    one-lane results -- on cyclotomic inputs for f^x (Granger-Scott squaring) and on raw Miller outputs for
+    the whole exponentiation (golden pairing values)."""
+    c = curve(cname)
+    mp = getattr(twin, "twin_multi_pairing_" + cname)
+    coop = getattr(twin, "twin_coop_" + cname)
+    expx = getattr(twin, "twin_exp_by_x_" + cname)
+    for e in c.golden["pairing"][:3]:
+        miller = np.zeros(12 * c.nq, dtype=np.uint64)
+        mp(1, ptr(c.g1(e["p"])), ptr(c.g2(e["q"])), ptr(miller), 0)
+        out3 = np.zeros(3 * 12 * c.nq, dtype=np.uint64)
+        coop(1, ptr(miller), ptr(out3))
+        for j in range(3):
+            assert c.f12_dec(out3.reshape(3, -1)[j]) == e["out"], j
+        # f^x on the (cyclotomic) pairing value itself
+        gt = c.f12(e["out"])
+        want = np.zeros(12 * c.nq, dtype=np.uint64)
+        expx(ptr(gt), ptr(want))
+        coop(0, ptr(gt), ptr(out3))
+        for j in range(3):
+            assert (out3.reshape(3, -1)[j] == want).all(), j

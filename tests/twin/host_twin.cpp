@@ -5,15 +5,55 @@
 // contract and every lazy add/sub asserts that int32 limbs would not overflow.
 // Test infrastructure only -- never loaded by the product.
 #include <string.h>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include "../../groth_sahai_rs_amd/csrc/gs_params_bls12_381.h"
 #include "../../groth_sahai_rs_amd/csrc/gs_params_bn254.h"
 #include "../../groth_sahai_rs_amd/csrc/gs_pairing.cuh"
+#include "../../groth_sahai_rs_amd/csrc/gs_coop.cuh"
 
 namespace gs {
 GS_ZERO_ONE(Bls12_381)
 GS_ZERO_ONE(Bn254)
 }
 using namespace gs;
+
+// The 3-lane cooperative exponentiation (gs_coop.cuh) on three host threads: the exchange policy is a
+// mailbox with a barrier where the device uses wave shuffles; the lane code is the device's.
+struct Barrier3 {
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0, phase = 0;
+  void wait() {
+    std::unique_lock<std::mutex> l(m);
+    int ph = phase;
+    if (++waiting == 3) {
+      waiting = 0;
+      phase++;
+      cv.notify_all();
+    } else {
+      cv.wait(l, [&] { return phase != ph; });
+    }
+  }
+};
+template <class C> struct CoopHost {
+  Fp4<C>* slots;
+  Barrier3* bar;
+  Fp4<C> swap12(const Fp4<C>& mine, int j) {
+    slots[j] = mine;
+    bar->wait();
+    Fp4<C> r = slots[j == 0 ? 0 : 3 - j];
+    bar->wait();
+    return r;
+  }
+  void gather(Fp4<C>* A, const Fp4<C>& mine, int j) {
+    slots[j] = mine;
+    bar->wait();
+    for (int i = 0; i < 3; i++) A[i] = slots[i];
+    bar->wait();
+  }
+};
 
 template <class C> struct Twin {
   typedef Fq<C> F1;
@@ -131,6 +171,30 @@ template <class C> struct Twin {
     }
     f12_to_boundary<C>((BFq<C>*)o, r);
   }
+  // what: 0 = f^x only, 1 = whole final exponentiation.  out = 3 GT values (one per lane; they must agree)
+  static void coop(int what, const uint8_t* in, uint8_t* out) {
+    Fp12<C> f;
+    f12_from_boundary<C>(f, (const BFq<C>*)in);
+    Fp4<C> slots[3];
+    Barrier3 bar;
+    Fp12<C> res[3];
+    std::thread th[3];
+    for (int j = 0; j < 3; j++)
+      th[j] = std::thread([&, j] {
+        CoopHost<C> xh{slots, &bar};
+        ExpXCoop<C, CoopHost<C>> ex{j, &xh};
+        if (what == 0) ex(res[j], f);
+        else final_exp_with(res[j], f, ex);
+      });
+    for (int j = 0; j < 3; j++) th[j].join();
+    for (int j = 0; j < 3; j++) f12_to_boundary<C>((BFq<C>*)out + 12 * j, res[j]);
+  }
+  static void exp_by_x(const uint8_t* in, uint8_t* out) {
+    Fp12<C> f, r;
+    f12_from_boundary<C>(f, (const BFq<C>*)in);
+    f12_exp_by_x(r, f);
+    f12_to_boundary<C>((BFq<C>*)out, r);
+  }
   static void multi_pairing(int np, const uint8_t* ps, const uint8_t* qs, uint8_t* o, int do_fe) {
     Aff<F1>* P = new Aff<F1>[np];
     Aff<F2>* Q = new Aff<F2>[np];
@@ -164,6 +228,8 @@ template <class C> struct Twin {
   void twin_fp12_op_##SUF(int op, const uint8_t* a, const uint8_t* b, uint8_t* o) {                              \
     Twin<CURVE>::fp12_op(op, a, b, o);                                                                            \
   }                                                                                                               \
+  void twin_coop_##SUF(int what, const uint8_t* in, uint8_t* out) { Twin<CURVE>::coop(what, in, out); }           \
+  void twin_exp_by_x_##SUF(const uint8_t* in, uint8_t* out) { Twin<CURVE>::exp_by_x(in, out); }                   \
   void twin_multi_pairing_##SUF(int np, const uint8_t* ps, const uint8_t* qs, uint8_t* o, int fe) {              \
     Twin<CURVE>::multi_pairing(np, ps, qs, o, fe);                                                                \
   }                                                                                                               \
