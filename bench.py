@@ -44,6 +44,66 @@ def cpu_baseline(sample_units, threads):
     }
 
 
+# measured v_mad_u64_u32 issue peak of the chip (tools/ubench.hip, profiles/r1/ubench_valu.txt: 4.34 cycles per
+# wave-instruction per SIMD at the 2.4 GHz the runtime reports, 1024 SIMDs x 64 lanes) in G lane-mads/s
+VALU_MAD_PEAK_G = 1024 * 64 * 2.4e9 / 4.34 / 1e9
+
+
+def alu_roofline(work, ms, curve_id, dominant):
+    """Useful Fq multiplications of one profiled step (per-kernel work items from gs_prof_get_work x the
+    per-primitive counts of profiles/r1/fq_mul_counts.json, tools/count_fq_muls.py) x 2 L^2 multiply-adds each,
+    against the measured v_mad_u64_u32 peak: SURVEY.md 8(d)'s ALU roofline.  Kernels without an entry (scalar
+    preparation, GT products, boundary conversions) count as zero, so the figure is a lower bound."""
+    try:
+        cnt = json.load(open(os.path.join(ROOT, "profiles", "r1", "fq_mul_counts.json")))[
+            "bls12_381" if curve_id == 0 else "bn254"]
+    except Exception as ex:  # the counts are a committed measurement artefact; without them report nothing
+        return {"error": "fq_mul_counts.json unavailable: %s" % ex}
+    muls = {}
+    partials = cells = 0
+    for name, (lanes, items) in work.items():
+        g = "g2" if name.endswith("g2") else "g1"
+        k = name.split(".")[0]
+        if k == "k_fix":
+            m = items * 32 * (255.0 / 256.0) * cnt[g + "_madd"]
+        elif k == "k_var":
+            m = lanes * cnt[g + "_smul"]
+        elif k in ("k_var_multi4", "k_var_multi8"):
+            m = items * cnt["%s_straus%s_per_term" % (g, k[-1])]
+        elif k == "k_red":
+            m = max(items - 2 * lanes, 0) * cnt[g + "_add"] + lanes * cnt[g + "_red_tail"]
+        elif name == "k_miller.twin":
+            m = lanes * cnt["miller2_per_lane"] + items * cnt["miller2_per_triple"]
+            partials += 2 * lanes
+        elif k == "k_miller":
+            m = lanes * cnt["miller_per_lane"] + items * cnt["miller_per_pair"]
+            partials += lanes
+        elif name == "k_final":
+            m = lanes * cnt["final_exp"]
+            cells += lanes
+        elif name == "k_final.coop":
+            m = lanes * cnt["final_exp_coop_lane"]
+            cells += lanes // 3
+        else:
+            continue
+        muls[name] = m
+    for name in ("k_final", "k_final.coop"):  # products of the Miller partials of each cell
+        if name in muls and partials > cells:
+            muls[name] += (partials - cells) * cnt["f12_mul"] * (3 if name.endswith("coop") else 1)
+    total = sum(muls.values())
+    step_s = sum(ms.values()) / 1e3
+    mads = cnt["mads_per_fq_mul"]
+    dom = {}
+    if dominant in muls and ms.get(dominant):
+        a = muls[dominant] * mads / (ms[dominant] / 1e3) / 1e9
+        dom = {"kernel": dominant, "achieved": a, "frac": a / VALU_MAD_PEAK_G}
+    a = total * mads / step_s / 1e9
+    return {"bound": "valu (v_mad_u64_u32 issue)", "achieved": a, "peak": VALU_MAD_PEAK_G, "unit": "G mad/s",
+            "frac": a / VALU_MAD_PEAK_G, "fq_muls_per_step": total, "mads_per_fq_mul": mads, "dominant": dom,
+            "fq_muls_by_kernel": {k: round(v) for k, v in muls.items()}}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +224,9 @@ def main():
                         traffic = v["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
+        alu = alu_roofline(eng.prof_get_work(), {p[0]: p[1] for p in prof}, args.curve, name)
+        if "fq_muls_per_step" in alu:
+            alu["fq_muls_per_unit"] = alu["fq_muls_per_step"] / N
         roof = {
             "bound": "hbm",
             "kernel": name,
@@ -176,7 +239,8 @@ def main():
             "bytes_per_unit": bpu,
             "kernel_share_of_step": ms / tot,
             "kernels_ms": {p[0]: round(p[1], 3) for p in prof},
-            "note": "integer-ALU bound path (SURVEY.md 8d): HBM fraction is ~1e-5 by construction",
+            "note": "integer-ALU bound path (SURVEY.md 8d): HBM fraction is ~1e-4 by construction; see alu",
+            "alu": alu,
         }
 
     total_units = N * world * args.steps

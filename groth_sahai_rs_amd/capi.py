@@ -22,7 +22,7 @@ SYMBOLS = [
     "gs_mat_left_mul_com1", "gs_mat_left_mul_com2", "gs_pairing_sum",
     "gs_g1_mul_batch", "gs_g2_mul_batch", "gs_g1_mul_batch_dev", "gs_g2_mul_batch_dev",
     "gs_multi_pairing_batch", "gs_multi_pairing_batch_dev", "gs_gt_pow_batch_dev",
-    "gs_prof_enable", "gs_prof_reset", "gs_prof_get",
+    "gs_prof_enable", "gs_prof_reset", "gs_prof_get", "gs_prof_get_work",
 ]
 
 
@@ -261,4 +261,13 @@ class Engine:
                 break
             out.append((name.value.decode(), ms.value, n.value))
             i += 1
+        return out
+
+    def prof_get_work(self):
+        """{kernel name: (lanes, work items)} for the kernels profiled since prof_reset()."""
+        out = {}
+        for i, (name, _, _) in enumerate(self.prof_get()):
+            lanes, work = ctypes.c_uint64(), ctypes.c_uint64()
+            self._chk(self.lib.gs_prof_get_work(self.ctx, i, ctypes.byref(lanes), ctypes.byref(work)))
+            out[name] = (lanes.value, work.value)
         return out

@@ -32,6 +32,8 @@ struct DevBuf {
 struct ProfEntry {
   double ms = 0;
   uint64_t n = 0;
+  uint64_t lanes = 0;  // lane-tasks launched
+  uint64_t work = 0;   // kernel-specific work items (scalars, slots, pairs ...; = lanes when no hint was given)
 };
 
 struct gs_ctx {
@@ -52,6 +54,7 @@ struct gs_ctx {
   std::map<std::string, ProfEntry> prof_map;
   std::vector<std::string> prof_order;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint64_t work_hint = 0;  // consumed by the next launch() while profiling
   // SIMD slots of the device (CUs x 4); every heavy kernel runs one 512-VGPR wave per SIMD
   size_t simd_slots = 1024;
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
@@ -109,7 +112,10 @@ static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, 
     ProfEntry& p = c->prof_map[name];
     p.ms += ms;
     p.n += 1;
+    p.lanes += total;
+    p.work += c->work_hint ? c->work_hint : total;
   }
+  c->work_hint = 0;
   return GS_OK;
 }
 #define RC(x)                 \
@@ -285,6 +291,11 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
   RC(upload(c, (t + ".red").c_str(), sp.red, &dred));
   void* part;
   RC(scratch(c, (t + ".part").c_str(), N * sp.nslots * sizeof(Jac<F>), &part));
+  {
+    uint64_t terms = 0;  // fixed-base scalars per equation
+    for (const FixTask& f : sp.fix) terms += (f.t0 != 0xFF) + (f.t1 != 0xFF);
+    c->work_hint = N * terms;
+  }
   RC(launch(c, (std::string("k_fix") + tag).c_str(), k_fix<C, F>, N * sp.fix.size(), 64, N * sp.fix.size(),
             (int)sp.fix.size(), dfix, arrs, pool, pool_n, tab, (Jac<F>*)part, sp.nslots));
   if (sp.tm <= 1) {
@@ -294,6 +305,7 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
     const GrpTask* dgrp;
     RC(upload(c, (t + ".grp").c_str(), sp.grp, &dgrp));
     size_t tot = N * sp.grp.size();
+    c->work_hint = N * sp.var.size();  // terms
     if (sp.tm <= 4)
       RC(launch(c, (std::string("k_var_multi4") + tag).c_str(), k_var_multi<C, F, 4>, tot, 64, tot, (int)sp.grp.size(),
                 dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
@@ -301,6 +313,7 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
       RC(launch(c, (std::string("k_var_multi8") + tag).c_str(), k_var_multi<C, F, 8>, tot, 64, tot, (int)sp.grp.size(),
                 dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
   }
+  c->work_hint = N * (uint64_t)sp.nslots;  // partial sums folded
   RC(launch(c, (std::string("k_red") + tag).c_str(), k_red<C, F>, N * sp.red.size(), 64, N * sp.red.size(),
             (int)sp.red.size(), dred, (const Jac<F>*)part, sp.nslots, outs));
   return GS_OK;
@@ -647,6 +660,11 @@ template <class C> struct Impl {
     qarr.stride[3] = (uint32_t)(kx * Z::COM2);
     qarr.base[4] = (const uint8_t*)target;
     qarr.stride[4] = (uint32_t)Z::G2;
+    {
+      uint64_t pairs = 0;  // (P, Q) pairs (twin: (Q, P0, P1) triples) per equation
+      for (const MillerTask& t : vp.mt) pairs += t.np;
+      c->work_hint = N * pairs;
+    }
     if (twin)
       RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2));
     else
@@ -857,6 +875,11 @@ template <class C> struct Impl {
     qarr.stride[3] = (uint32_t)(kx * Z::COM2);
     qarr.base[4] = (const uint8_t*)target;
     qarr.stride[4] = (uint32_t)Z::G2;
+    {
+      uint64_t pairs = 0;
+      for (const MillerTask& t : mt) pairs += t.np;
+      c->work_hint = N * pairs;
+    }
     RC(launch(c, "k_miller.rlc", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 1));
     uint8_t* a = (uint8_t*)acc;
     RC(gt_product(c, N * ntask, (GT*)mpart, (GT*)tmp, a));
@@ -1390,6 +1413,13 @@ int gs_prof_get(gs_ctx* c, int idx, char* name, size_t cap, double* ms, uint64_t
   }
   if (ms) *ms = c->prof_map[k].ms;
   if (n) *n = c->prof_map[k].n;
+  return GS_OK;
+}
+int gs_prof_get_work(gs_ctx* c, int idx, uint64_t* lanes, uint64_t* work) {
+  if (!c || idx < 0 || (size_t)idx >= c->prof_order.size()) return GS_ERR_ARG;
+  const ProfEntry& p = c->prof_map[c->prof_order[idx]];
+  if (lanes) *lanes = p.lanes;
+  if (work) *work = p.work;
   return GS_OK;
 }
 

@@ -26,6 +26,7 @@
 #if defined(GS_FQ28_CHECK)
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #endif
 
 namespace gs {
@@ -185,7 +186,14 @@ template <class C, class T> GS_HD void mul28_generic(T* r, const T* a, const T* 
 }
 
 #if defined(GS_FQ28_CHECK)
+// CPU twin only: number of Fq multiplications executed (feeds the ALU roofline of bench.py through
+// tools/count_fq_muls.py)
+inline std::atomic<long>& fq28_mul_counter() {
+  static std::atomic<long> n{0};
+  return n;
+}
 template <class C> inline void fq28_check(const Fq28<C>& a, const Fq28<C>& b) {
+  fq28_mul_counter().fetch_add(1, std::memory_order_relaxed);
   int64_t ma = 0, mb = 0;
   for (int i = 0; i < C::L; i++) {
     int64_t x = a.v[i] < 0 ? -(int64_t)a.v[i] : a.v[i], y = b.v[i] < 0 ? -(int64_t)b.v[i] : b.v[i];

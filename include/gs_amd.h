@@ -150,6 +150,9 @@ int gs_gt_pow_batch_dev(gs_ctx*, size_t count, const void* base_gt_dev, const vo
 int gs_prof_enable(gs_ctx*, int on);
 int gs_prof_reset(gs_ctx*);
 int gs_prof_get(gs_ctx*, int idx, char* name, size_t name_cap, double* total_ms, uint64_t* launches);
+/* lane-tasks launched under that name and its kernel-specific work items (fixed-base scalars for k_fix, terms for
+ * k_var_multi, partial sums for k_red, pairs for k_miller, lanes otherwise): inputs of bench.py's ALU roofline */
+int gs_prof_get_work(gs_ctx*, int idx, uint64_t* lanes, uint64_t* work);
 
 #ifdef __cplusplus
 }

@@ -145,6 +145,14 @@ template <class C> struct Twin {
     jac_to_aff(R, J);
     stg1(o, R);
   }
+  static void g1_to_aff(const uint8_t* p, uint8_t* o) {  // Jacobian -> affine normalisation (one inversion)
+    Aff<F1> P = ldg1(p), R;
+    Jac<F1> J;
+    jac_from_aff(J, P);
+    jac_dbl(J, J);
+    jac_to_aff(R, J);
+    stg1(o, R);
+  }
   static void g2_madd(const uint8_t* p, const uint8_t* q, uint8_t* o) {
     Aff<F2> P = ldg2(p), Q = ldg2(q), R;
     Jac<F2> J;
@@ -195,6 +203,89 @@ template <class C> struct Twin {
     f12_exp_by_x(r, f);
     f12_to_boundary<C>((BFq<C>*)out, r);
   }
+  // Fq multiplications one device primitive executes (tools/count_fq_muls.py -> bench.py's ALU roofline).
+  // g1/g2: nt affine points, k: nt Montgomery scalars.
+  static long opcount(int op, int nt, const uint8_t* g1, const uint8_t* g2, const uint32_t* k_mont) {
+    Aff<F1> P[8];
+    Aff<F2> Q[8];
+    Fr<C> k[8];
+    for (int i = 0; i < nt && i < 8; i++) {
+      P[i] = ldg1(g1 + i * 2 * NB);
+      Q[i] = ldg2(g2 + i * 4 * NB);
+      Fr<C> t;
+      memcpy(&t, k_mont + i * 8, sizeof t);
+      k[i] = from_mont(t);
+    }
+    Jac<F1> J1, K1;
+    Jac<F2> J2, K2;
+    jac_from_aff(J1, P[0]);
+    jac_dbl(J1, J1);
+    jac_from_aff(K1, P[1 % (nt ? nt : 1)]);
+    jac_dbl(K1, K1);
+    jac_madd(K1, K1, P[0]);
+    jac_from_aff(J2, Q[0]);
+    jac_dbl(J2, J2);
+    jac_from_aff(K2, Q[1 % (nt ? nt : 1)]);
+    jac_dbl(K2, K2);
+    jac_madd(K2, K2, Q[0]);
+    Fp12<C> f, g;
+    {
+      Proj2<C> T[8];
+      bool live[8];
+      multi_miller(f, P, Q, 1, T, live);
+    }
+    long c0 = fq28_mul_counter().load();
+    switch (op) {
+      case 0: jac_smul_any<C>(J1, P[0], k[0]); break;
+      case 1: jac_smul_any<C>(J2, Q[0], k[0]); break;
+      case 2: if (nt <= 4) jac_msm_straus<C, F1, 4>(J1, P, k, nt); else jac_msm_straus<C, F1, 8>(J1, P, k, nt); break;
+      case 3: if (nt <= 4) jac_msm_straus<C, F2, 4>(J2, Q, k, nt); else jac_msm_straus<C, F2, 8>(J2, Q, k, nt); break;
+      case 4: jac_madd(J1, J1, P[0]); break;
+      case 5: jac_madd(J2, J2, Q[0]); break;
+      case 6: jac_add(J1, J1, K1); break;
+      case 7: jac_add(J2, J2, K2); break;
+      case 8: {  // tail of k_red: one inversion for two points
+        F1 zi = inv(mul(J1.z, K1.z));
+        F1 a = mul(zi, K1.z), b = mul(zi, J1.z);
+        Aff<F1> r0, r1;
+        jac_to_aff_zinv(r0, J1, a);
+        jac_to_aff_zinv(r1, K1, b);
+        break;
+      }
+      case 9: {
+        F2 zi = inv(mul(J2.z, K2.z));
+        F2 a = mul(zi, K2.z), b = mul(zi, J2.z);
+        Aff<F2> r0, r1;
+        jac_to_aff_zinv(r0, J2, a);
+        jac_to_aff_zinv(r1, K2, b);
+        break;
+      }
+      case 10: {
+        Proj2<C> T[8];
+        bool live[8];
+        multi_miller(g, P, Q, nt, T, live);
+        break;
+      }
+      case 14: {  // twin Miller: nt (Q, P0, P1) triples, two accumulators
+        Proj2<C> T[8];
+        uint8_t live[8];
+        Fp12<C> g1v;
+        multi_miller2(g, g1v, P, P, Q, nt, T, live);
+        break;
+      }
+      case 11: f12_mul(g, f, f); break;
+      case 12: final_exp(g, f); break;
+      case 13: {  // whole 3-lane group (divide by 3 for one lane)
+        uint8_t in[12 * NB], out[3 * 12 * NB];
+        f12_to_boundary<C>((BFq<C>*)in, f);
+        c0 = fq28_mul_counter().load();
+        coop(1, in, out);
+        return fq28_mul_counter().load() - c0 - 3 * 12 - 12;  // minus the boundary conversions of this harness
+      }
+      default: break;
+    }
+    return fq28_mul_counter().load() - c0;
+  }
   static void multi_pairing(int np, const uint8_t* ps, const uint8_t* qs, uint8_t* o, int do_fe) {
     Aff<F1>* P = new Aff<F1>[np];
     Aff<F2>* Q = new Aff<F2>[np];
@@ -212,6 +303,12 @@ template <class C> struct Twin {
   }
 };
 
+extern "C" long twin_fq_mul_count(int reset) {
+  long v = fq28_mul_counter().load();
+  if (reset) fq28_mul_counter().store(0);
+  return v;
+}
+
 #define EXPORT(SUF, CURVE)                                                                                        \
   extern "C" {                                                                                                    \
   void twin_fp_mul_##SUF(const uint8_t* a, const uint8_t* b, uint8_t* o) { Twin<CURVE>::fp_mul(a, b, o); }       \
@@ -224,9 +321,13 @@ template <class C> struct Twin {
   void twin_g1_msm_##SUF(int nt, const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g1_msm(nt, p, k, o); } \
   void twin_g2_msm_##SUF(int nt, const uint8_t* p, const uint32_t* k, uint8_t* o) { Twin<CURVE>::g2_msm(nt, p, k, o); } \
   void twin_g1_add_##SUF(const uint8_t* p, const uint8_t* q, uint8_t* o) { Twin<CURVE>::g1_add(p, q, o); }       \
+  void twin_g1_to_aff_##SUF(const uint8_t* p, uint8_t* o) { Twin<CURVE>::g1_to_aff(p, o); }                       \
   void twin_g2_madd_##SUF(const uint8_t* p, const uint8_t* q, uint8_t* o) { Twin<CURVE>::g2_madd(p, q, o); }     \
   void twin_fp12_op_##SUF(int op, const uint8_t* a, const uint8_t* b, uint8_t* o) {                              \
     Twin<CURVE>::fp12_op(op, a, b, o);                                                                            \
+  }                                                                                                               \
+  long twin_opcount_##SUF(int op, int nt, const uint8_t* g1, const uint8_t* g2, const uint32_t* k) {              \
+    return Twin<CURVE>::opcount(op, nt, g1, g2, k);                                                                \
   }                                                                                                               \
   void twin_coop_##SUF(int what, const uint8_t* in, uint8_t* out) { Twin<CURVE>::coop(what, in, out); }           \
   void twin_exp_by_x_##SUF(const uint8_t* in, uint8_t* out) { Twin<CURVE>::exp_by_x(in, out); }                   \
