@@ -22,6 +22,8 @@ SYMBOLS = [
     "gs_mat_left_mul_com1", "gs_mat_left_mul_com2", "gs_pairing_sum",
     "gs_g1_mul_batch", "gs_g2_mul_batch", "gs_g1_mul_batch_dev", "gs_g2_mul_batch_dev",
     "gs_multi_pairing_batch", "gs_multi_pairing_batch_dev", "gs_gt_pow_batch_dev",
+    "gs_wire_sizes", "gs_wire_encode_g1", "gs_wire_encode_g2", "gs_wire_decode_g1", "gs_wire_decode_g2",
+    "gs_wire_encode_fr", "gs_wire_decode_fr", "gs_wire_encode_gt", "gs_wire_decode_gt",
     "gs_prof_enable", "gs_prof_reset", "gs_prof_get", "gs_prof_get_work",
 ]
 
@@ -242,6 +244,52 @@ class Engine:
 
     def gt_pow_batch_dev(self, n, base, k, out):
         self._chk(self.lib.gs_gt_pow_batch_dev(self.ctx, ctypes.c_size_t(n), _p(base), _p(k), _p(out)))
+
+    # -- wire format (ark-serialize byte strings <-> boundary arrays) -------------------
+    def wire_sizes(self):
+        out = (ctypes.c_size_t * 6)()
+        self._chk(self.lib.gs_wire_sizes(self.curve, out))
+        return dict(zip(("g1c", "g1u", "g2c", "g2u", "fr", "gt"), [int(v) for v in out]))
+
+    def wire_encode(self, kind, arr, compressed=True):
+        """kind in g1|g2|fr|gt; arr: (n, element bytes) boundary values -> (n, wire bytes) uint8."""
+        ws = self.wire_sizes()
+        arr = np.ascontiguousarray(arr).view(np.uint8)
+        esz = {"g1": self.G1, "g2": self.G2, "fr": self.FR, "gt": self.GT}[kind]
+        n = arr.size // esz
+        wsz = ws[kind + ("c" if compressed else "u")] if kind in ("g1", "g2") else ws[kind]
+        out = np.zeros((n, wsz), dtype=np.uint8)
+        if n == 0:
+            return out
+        if kind in ("g1", "g2"):
+            fn = self.lib.gs_wire_encode_g1 if kind == "g1" else self.lib.gs_wire_encode_g2
+            self._chk(fn(self.ctx, ctypes.c_size_t(n), 1 if compressed else 0, _p(arr), _p(out)))
+        else:
+            fn = self.lib.gs_wire_encode_fr if kind == "fr" else self.lib.gs_wire_encode_gt
+            self._chk(fn(self.ctx, ctypes.c_size_t(n), _p(arr), _p(out)))
+        return out
+
+    def wire_decode(self, kind, buf, compressed=True, validate=True):
+        """-> (values (n, element bytes) uint8, ok (n,) uint8)."""
+        ws = self.wire_sizes()
+        buf = np.ascontiguousarray(buf).view(np.uint8)
+        esz = {"g1": self.G1, "g2": self.G2, "fr": self.FR, "gt": self.GT}[kind]
+        wsz = ws[kind + ("c" if compressed else "u")] if kind in ("g1", "g2") else ws[kind]
+        n = buf.size // wsz
+        out = np.zeros((n, esz), dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        if n == 0:
+            return out, ok
+        if kind in ("g1", "g2"):
+            fn = self.lib.gs_wire_decode_g1 if kind == "g1" else self.lib.gs_wire_decode_g2
+            self._chk(fn(self.ctx, ctypes.c_size_t(n), 1 if compressed else 0, 1 if validate else 0, _p(buf), _p(out),
+                         _p(ok)))
+        elif kind == "fr":
+            self._chk(self.lib.gs_wire_decode_fr(self.ctx, ctypes.c_size_t(n), _p(buf), _p(out), _p(ok)))
+        else:
+            self._chk(self.lib.gs_wire_decode_gt(self.ctx, ctypes.c_size_t(n), 1 if validate else 0, _p(buf), _p(out),
+                                                 _p(ok)))
+        return out, ok
 
     # -- profiling hook ---------------------------------------------------------------
     def prof_enable(self, on=True):

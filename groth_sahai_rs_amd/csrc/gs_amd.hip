@@ -1019,6 +1019,67 @@ static int left_mul_impl(gs_ctx* c, int rows, int k, const void* lhs, const void
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+// ---- wire format (gs_wire.cuh): arrays of elements, host pointers -------------------------------------
+template <class C> struct WireImpl {
+  typedef Fq<C> F1;
+  typedef Fp2<C> F2;
+  template <class F> static int enc_pts(gs_ctx* c, size_t n, int compressed, const void* pts, uint8_t* out) {
+    if (n == 0) return GS_OK;
+    size_t pb = AFFB(C, F), wb = wire_point_bytes<C, F>(compressed != 0);
+    HostStage st(c);
+    void *din, *dout;
+    RC(st.in(pts, n * pb, &din));
+    RC(st.out(out, n * wb, &dout));
+    RC(launch(c, "k_wire_enc_pts", k_wire_enc_pts<C, F>, n, 64, n, (const uint8_t*)din, compressed, (uint8_t*)dout));
+    return st.back(out, dout, n * wb);
+  }
+  template <class F>
+  static int dec_pts(gs_ctx* c, size_t n, int compressed, int validate, const uint8_t* in, void* pts, uint8_t* ok) {
+    if (n == 0) return GS_OK;
+    size_t pb = AFFB(C, F), wb = wire_point_bytes<C, F>(compressed != 0);
+    HostStage st(c);
+    void *din, *dout, *dok;
+    RC(st.in(in, n * wb, &din));
+    RC(st.out(pts, n * pb, &dout));
+    RC(st.out(ok, n, &dok));
+    RC(launch(c, "k_wire_dec_pts", k_wire_dec_pts<C, F>, n, 64, n, (const uint8_t*)din, compressed, validate,
+              (uint8_t*)dout, (uint8_t*)dok));
+    RC(st.back(pts, dout, n * pb));
+    return st.back(ok, dok, n);
+  }
+  // what: 0 Fr, 1 GT
+  static int fields(gs_ctx* c, int what, int dir, int validate, size_t n, const void* in, void* out, uint8_t* ok) {
+    if (n == 0) return GS_OK;
+    size_t per = what == 0 ? 1 : 12, eb = what == 0 ? sizeof(Fr<C>) : 4 * C::N, cnt = n * per;
+    HostStage st(c);
+    void *din, *dout, *dok = nullptr;
+    RC(st.in(in, cnt * eb, &din));
+    RC(st.out(out, cnt * eb, &dout));
+    std::vector<uint8_t> oks(cnt, 1);
+    if (dir == 1) RC(st.out(oks.data(), cnt, &dok));
+    if (what == 0)
+      RC(launch(c, "k_wire_fr", k_wire_fr<C>, cnt, 64, cnt, dir, (const uint8_t*)din, (uint8_t*)dout, (uint8_t*)dok));
+    else
+      RC(launch(c, "k_wire_fq", k_wire_fq<C>, cnt, 64, cnt, dir, (const uint8_t*)din, (uint8_t*)dout, (uint8_t*)dok));
+    RC(st.back(out, dout, cnt * eb));
+    if (dir == 1) {
+      RC(st.back(oks.data(), dok, cnt));
+      for (size_t i = 0; i < n; i++) {
+        uint8_t a = 1;
+        for (size_t j = 0; j < per; j++) a &= oks[i * per + j];
+        ok[i] = a;
+      }
+      if (what == 1 && validate) {  // PairingOutput validity: f^r = 1
+        void* dok2;
+        RC(st.in(ok, n, &dok2));
+        RC(launch(c, "k_wire_gt_check", k_wire_gt_check<C>, n, 64, n, (const uint8_t*)dout, (uint8_t*)dok2));
+        RC(st.back(ok, dok2, n));
+      }
+    }
+    return GS_OK;
+  }
+};
+
 extern "C" {
 
 const char* gs_version(void) { return GS_VERSION; }
@@ -1393,6 +1454,62 @@ int gs_gt_finalize(gs_ctx* c, size_t count, const void* accs, uint8_t* ok) {
 }
 
 // ---- profiling ---------------------------------------------------------------------
+#define WIRE_DISPATCH(expr_bls, expr_bn) (c->curve == 0 ? (expr_bls) : (expr_bn))
+
+int gs_wire_sizes(int curve, size_t out[6]) {
+  if ((curve != 0 && curve != 1) || !out) return GS_ERR_ARG;
+  size_t fq = sz_fq(curve);
+  out[0] = fq;       // G1 compressed
+  out[1] = 2 * fq;   // G1 uncompressed
+  out[2] = 2 * fq;   // G2 compressed
+  out[3] = 4 * fq;   // G2 uncompressed
+  out[4] = SZ_FR;    // Fr
+  out[5] = 12 * fq;  // GT
+  return GS_OK;
+}
+int gs_wire_encode_g1(gs_ctx* c, size_t n, int compressed, const void* pts, uint8_t* out) {
+  RC(check_ctx(c, false));
+  return WIRE_DISPATCH((WireImpl<Bls12_381>::enc_pts<Fq<Bls12_381>>(c, n, compressed, pts, out)),
+                       (WireImpl<Bn254>::enc_pts<Fq<Bn254>>(c, n, compressed, pts, out)));
+}
+int gs_wire_encode_g2(gs_ctx* c, size_t n, int compressed, const void* pts, uint8_t* out) {
+  RC(check_ctx(c, false));
+  return WIRE_DISPATCH((WireImpl<Bls12_381>::enc_pts<Fp2<Bls12_381>>(c, n, compressed, pts, out)),
+                       (WireImpl<Bn254>::enc_pts<Fp2<Bn254>>(c, n, compressed, pts, out)));
+}
+int gs_wire_decode_g1(gs_ctx* c, size_t n, int compressed, int validate, const uint8_t* in, void* pts, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  return WIRE_DISPATCH((WireImpl<Bls12_381>::dec_pts<Fq<Bls12_381>>(c, n, compressed, validate, in, pts, ok)),
+                       (WireImpl<Bn254>::dec_pts<Fq<Bn254>>(c, n, compressed, validate, in, pts, ok)));
+}
+int gs_wire_decode_g2(gs_ctx* c, size_t n, int compressed, int validate, const uint8_t* in, void* pts, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  return WIRE_DISPATCH((WireImpl<Bls12_381>::dec_pts<Fp2<Bls12_381>>(c, n, compressed, validate, in, pts, ok)),
+                       (WireImpl<Bn254>::dec_pts<Fp2<Bn254>>(c, n, compressed, validate, in, pts, ok)));
+}
+int gs_wire_encode_fr(gs_ctx* c, size_t n, const void* fr, uint8_t* out) {
+  RC(check_ctx(c, false));
+  return WIRE_DISPATCH(WireImpl<Bls12_381>::fields(c, 0, 0, 0, n, fr, out, nullptr),
+                       WireImpl<Bn254>::fields(c, 0, 0, 0, n, fr, out, nullptr));
+}
+int gs_wire_decode_fr(gs_ctx* c, size_t n, const uint8_t* in, void* fr, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  if (!ok) return GS_ERR_ARG;
+  return WIRE_DISPATCH(WireImpl<Bls12_381>::fields(c, 0, 1, 0, n, in, fr, ok),
+                       WireImpl<Bn254>::fields(c, 0, 1, 0, n, in, fr, ok));
+}
+int gs_wire_encode_gt(gs_ctx* c, size_t n, const void* gt, uint8_t* out) {
+  RC(check_ctx(c, false));
+  return WIRE_DISPATCH(WireImpl<Bls12_381>::fields(c, 1, 0, 0, n, gt, out, nullptr),
+                       WireImpl<Bn254>::fields(c, 1, 0, 0, n, gt, out, nullptr));
+}
+int gs_wire_decode_gt(gs_ctx* c, size_t n, int validate, const uint8_t* in, void* gt, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  if (!ok) return GS_ERR_ARG;
+  return WIRE_DISPATCH(WireImpl<Bls12_381>::fields(c, 1, 1, validate, n, in, gt, ok),
+                       WireImpl<Bn254>::fields(c, 1, 1, validate, n, in, gt, ok));
+}
+
 int gs_prof_enable(gs_ctx* c, int on) {
   if (!c) return GS_ERR_ARG;
   c->prof = on != 0;

@@ -16,6 +16,7 @@
 #pragma once
 #include "gs_pairing.cuh"
 #include "gs_coop.cuh"
+#include "gs_wire.cuh"
 
 namespace gs {
 
@@ -588,6 +589,84 @@ template <class C> __global__ void k_gt_set_one(Fp12<C>* p) {
   Fp12<C> o;
   f12_one(o);
   p[0] = o;
+}
+
+// --------------------------------------------------------------------------
+// wire format (gs_wire.cuh): arrays of elements, one lane per element
+// --------------------------------------------------------------------------
+template <class C, class F> constexpr size_t wire_point_bytes(bool compressed) {
+  return (size_t)(compressed ? 1 : 2) * NCoord<F>::V * C::N * 4;
+}
+template <class C, class F>
+__global__ void __launch_bounds__(64, GS_WPE) k_wire_enc_pts(size_t n, const uint8_t* pts, int compressed, uint8_t* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Aff<F> p;
+  aff_load<C>(p, pts + g * AFFB(C, F));
+  wire_encode_point<C, F>(out + g * wire_point_bytes<C, F>(compressed != 0), p, compressed != 0);
+}
+template <class C, class F>
+__global__ void __launch_bounds__(64, GS_WPE) k_wire_dec_pts(size_t n, const uint8_t* in, int compressed, int validate,
+                                                     uint8_t* pts, uint8_t* ok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Aff<F> p;
+  bool good = wire_decode_point<C, F>(p, in + g * wire_point_bytes<C, F>(compressed != 0), compressed != 0, validate != 0);
+  aff_store<C>(pts + g * AFFB(C, F), p);
+  ok[g] = good ? 1 : 0;
+}
+// Fq arrays (GT = 12 per element): dir 0 boundary -> canonical little-endian bytes, dir 1 back (ok = canonical)
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE) k_wire_fq(size_t n, int dir, const uint8_t* in, uint8_t* out, uint8_t* ok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  constexpr int B = C::N * 4;
+  uint32_t w[C::N];
+  if (dir == 0) {
+    BFq<C> b = reinterpret_cast<const BFq<C>*>(in)[g];
+    fq_to_canonical<C>(w, fq_from_boundary<C>(b.w));
+    for (int i = 0; i < B; i++) out[g * B + i] = (uint8_t)(w[i >> 2] >> ((i & 3) * 8));
+  } else {
+    for (int i = 0; i < C::N; i++) w[i] = 0;
+    for (int i = 0; i < B; i++) w[i >> 2] |= (uint32_t)in[g * B + i] << ((i & 3) * 8);
+    bool canon = words_lt_p<C>(w);
+    BFq<C> b;
+    if (!canon)
+      for (int i = 0; i < C::N; i++) w[i] = 0;
+    fq_to_boundary<C>(b.w, fq_from_canonical<C>(w));
+    reinterpret_cast<BFq<C>*>(out)[g] = b;
+    ok[g] = canon ? 1 : 0;
+  }
+}
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE) k_wire_fr(size_t n, int dir, const uint8_t* in, uint8_t* out, uint8_t* ok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  constexpr int NW = FrM<C>::N, B = NW * 4;
+  if (dir == 0) {
+    Fr<C> k = from_mont(reinterpret_cast<const Fr<C>*>(in)[g]);
+    for (int i = 0; i < B; i++) out[g * B + i] = (uint8_t)(k.v[i >> 2] >> ((i & 3) * 8));
+  } else {
+    Fr<C> k;
+    uint32_t r[NW];
+    for (int i = 0; i < NW; i++) {
+      k.v[i] = 0;
+      r[i] = C::R_WORDS[i];
+    }
+    for (int i = 0; i < B; i++) k.v[i >> 2] |= (uint32_t)in[g * B + i] << ((i & 3) * 8);
+    bool canon = words_gt<NW>(r, k.v);
+    if (!canon)
+      for (int i = 0; i < NW; i++) k.v[i] = 0;
+    reinterpret_cast<Fr<C>*>(out)[g] = to_mont(k);
+    ok[g] = canon ? 1 : 0;
+  }
+}
+template <class C> __global__ void __launch_bounds__(64, GS_WPE) k_wire_gt_check(size_t n, const uint8_t* gt, uint8_t* ok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Fp12<C> f;
+  f12_from_boundary<C>(f, reinterpret_cast<const BFq<C>*>(gt) + 12 * g);
+  ok[g] = (ok[g] && f12_in_torsion(f)) ? 1 : 0;
 }
 
 }  // namespace gs

@@ -144,6 +144,27 @@ int gs_multi_pairing_batch_dev(gs_ctx*, size_t count, int k, const void* p_g1, c
 /* out[i] = base^(k[i]) in GT (k canonical-Montgomery Fr); used to synthesise satisfied PPE targets */
 int gs_gt_pow_batch_dev(gs_ctx*, size_t count, const void* base_gt_dev, const void* k_fr, void* out_gt);
 
+/* ---- canonical wire format (ark-serialize) -----------------------------------
+ * Arrays of elements between the boundary form above and the byte strings ark-serialize produces for
+ * the reference's derives (src/data_structures.rs:128,132 Com1/Com2; src/prover/commit.rs:18,24;
+ * src/prover/prove.rs:55; src/statement.rs:117-179; src/generator.rs:35): Fr / Fq little-endian canonical
+ * integers; GT = 12 Fq; BLS12-381 points in ark-bls12-381's zcash-compatible big-endian flagged form,
+ * BN254 points in ark-ec's default little-endian flagged form (details: csrc/gs_wire.cuh).  Struct
+ * framing (Vec<T> = u64-LE length + items, fields in declaration order, EquType = 1 byte) is host-side:
+ * include/gs_amd.hpp, groth_sahai_rs_amd/wire.py.  Host pointers.  decode: ok[i] = 1 iff element i is a
+ * well-formed encoding (canonical coordinates, consistent flags, on the curve) and, with validate != 0,
+ * passes the r-torsion check of ark-serialize's Validate::Yes; rejected elements decode to the identity
+ * (points) / zero.  sizes: out[0..5] = G1 compressed, G1 uncompressed, G2 compressed, G2 uncompressed, Fr, GT. */
+int gs_wire_sizes(int curve_id, size_t out[6]);
+int gs_wire_encode_g1(gs_ctx*, size_t n, int compressed, const void* pts_g1, uint8_t* out);
+int gs_wire_encode_g2(gs_ctx*, size_t n, int compressed, const void* pts_g2, uint8_t* out);
+int gs_wire_decode_g1(gs_ctx*, size_t n, int compressed, int validate, const uint8_t* in, void* pts_g1, uint8_t* ok);
+int gs_wire_decode_g2(gs_ctx*, size_t n, int compressed, int validate, const uint8_t* in, void* pts_g2, uint8_t* ok);
+int gs_wire_encode_fr(gs_ctx*, size_t n, const void* fr, uint8_t* out);
+int gs_wire_decode_fr(gs_ctx*, size_t n, const uint8_t* in, void* fr, uint8_t* ok);
+int gs_wire_encode_gt(gs_ctx*, size_t n, const void* gt, uint8_t* out);
+int gs_wire_decode_gt(gs_ctx*, size_t n, int validate, const uint8_t* in, void* gt, uint8_t* ok);
+
 /* ---- measurement hook ----------------------------------------------------
  * Name and average duration (ms, HIP events on the context's stream) of the
  * kernels launched since gs_prof_reset; used by bench.py for the roofline. */

@@ -12,6 +12,7 @@
 #include "../../groth_sahai_rs_amd/csrc/gs_params_bn254.h"
 #include "../../groth_sahai_rs_amd/csrc/gs_pairing.cuh"
 #include "../../groth_sahai_rs_amd/csrc/gs_coop.cuh"
+#include "../../groth_sahai_rs_amd/csrc/gs_wire.cuh"
 
 namespace gs {
 GS_ZERO_ONE(Bls12_381)
@@ -179,6 +180,24 @@ template <class C> struct Twin {
     }
     f12_to_boundary<C>((BFq<C>*)o, r);
   }
+  // wire format of points (gs_wire.cuh): boundary affine <-> bytes
+  static void wire_enc(int group, int compressed, const uint8_t* pt, uint8_t* out) {
+    if (group == 1) wire_encode_point<C, F1>(out, ldg1(pt), compressed != 0);
+    else wire_encode_point<C, F2>(out, ldg2(pt), compressed != 0);
+  }
+  static int wire_dec(int group, int compressed, int validate, const uint8_t* in, uint8_t* pt) {
+    bool ok;
+    if (group == 1) {
+      Aff<F1> p;
+      ok = wire_decode_point<C, F1>(p, in, compressed != 0, validate != 0);
+      stg1(pt, p);
+    } else {
+      Aff<F2> p;
+      ok = wire_decode_point<C, F2>(p, in, compressed != 0, validate != 0);
+      stg2(pt, p);
+    }
+    return ok ? 1 : 0;
+  }
   // what: 0 = f^x only, 1 = whole final exponentiation.  out = 3 GT values (one per lane; they must agree)
   static void coop(int what, const uint8_t* in, uint8_t* out) {
     Fp12<C> f;
@@ -328,6 +347,10 @@ extern "C" long twin_fq_mul_count(int reset) {
   }                                                                                                               \
   long twin_opcount_##SUF(int op, int nt, const uint8_t* g1, const uint8_t* g2, const uint32_t* k) {              \
     return Twin<CURVE>::opcount(op, nt, g1, g2, k);                                                                \
+  }                                                                                                               \
+  void twin_wire_enc_##SUF(int g, int c, const uint8_t* pt, uint8_t* out) { Twin<CURVE>::wire_enc(g, c, pt, out); }  \
+  int twin_wire_dec_##SUF(int g, int c, int v, const uint8_t* in, uint8_t* pt) {                                  \
+    return Twin<CURVE>::wire_dec(g, c, v, in, pt);                                                                 \
   }                                                                                                               \
   void twin_coop_##SUF(int what, const uint8_t* in, uint8_t* out) { Twin<CURVE>::coop(what, in, out); }           \
   void twin_exp_by_x_##SUF(const uint8_t* in, uint8_t* out) { Twin<CURVE>::exp_by_x(in, out); }                   \
