@@ -55,7 +55,8 @@ enum class EquType : uint8_t { PairingProduct = 0, MultiScalarG1 = 1, MultiScala
 struct Ctx {
   gs_ctx* c = nullptr;
   size_t sz[6] = {0, 0, 0, 0, 0, 0};  // Fq, Fr, G1, G2, GT, CRS
-  Ctx(int curve, int device) {
+  int curve_id = 0;
+  Ctx(int curve, int device) : curve_id(curve) {
     if (gs_sizes(curve, sz) != GS_OK) throw std::runtime_error("bad curve id");
     int rc = gs_ctx_create(curve, device, &c);
     if (rc != GS_OK) throw std::runtime_error("gs_ctx_create failed (no usable GPU; there is no CPU fallback)");
@@ -289,5 +290,280 @@ using PPE = Equation<G1Affine, G2Affine, GT, EquType::PairingProduct>;
 using MSMEG1 = Equation<G1Affine, Fr, G1Affine, EquType::MultiScalarG1>;
 using MSMEG2 = Equation<Fr, G2Affine, G2Affine, EquType::MultiScalarG2>;
 using QuadEqu = Equation<Fr, Fr, Fr, EquType::Quadratic>;
+
+// ---- canonical wire format (ark-serialize; the derives at data_structures.rs:128,132, commit.rs:18,24,
+// prove.rs:55, statement.rs:117-179, generator.rs:35).  Framing here, element codecs in the library
+// (gs_wire_*).  serialize_compressed / serialize_uncompressed / deserialize_compressed<T> /
+// deserialize_uncompressed<T> follow ark-serialize's names; deserialisation validates like Validate::Yes
+// and throws SerializationError where arkworks returns SerializationError::InvalidData.
+struct SerializationError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+namespace wire {
+enum Kind { K_G1 = 0, K_G2 = 1, K_FR = 2, K_GT = 3, K_RAW = 4 };
+inline size_t elem_size(const Ctx& cx, Kind k) {  // boundary bytes
+  return k == K_G1 ? cx.sz[2] : k == K_G2 ? cx.sz[3] : k == K_FR ? cx.sz[1] : cx.sz[4];
+}
+inline size_t wire_size(const Ctx& cx, Kind k, bool compressed) {
+  size_t w[6];
+  gs_wire_sizes(cx.curve_id, w);
+  return k == K_G1 ? w[compressed ? 0 : 1] : k == K_G2 ? w[compressed ? 2 : 3] : k == K_FR ? w[4] : w[5];
+}
+
+struct Writer {
+  struct Leaf {
+    Kind k;
+    Bytes v;
+  };
+  std::vector<Leaf> leaves;
+  void raw(Bytes b) { leaves.push_back({K_RAW, std::move(b)}); }
+  void len(size_t n) {
+    Bytes b(8);
+    for (int i = 0; i < 8; i++) b[i] = (uint8_t)((uint64_t)n >> (8 * i));
+    raw(b);
+  }
+  void put(const G1Affine& x) { leaves.push_back({K_G1, x.v}); }
+  void put(const G2Affine& x) { leaves.push_back({K_G2, x.v}); }
+  void put(const Fr& x) { leaves.push_back({K_FR, x.v}); }
+  void put(const GT& x) { leaves.push_back({K_GT, x.v}); }
+  void put(const Com1& c) {
+    size_t h = c.v.size() / 2;
+    leaves.push_back({K_G1, Bytes(c.v.begin(), c.v.begin() + h)});
+    leaves.push_back({K_G1, Bytes(c.v.begin() + h, c.v.end())});
+  }
+  void put(const Com2& c) {
+    size_t h = c.v.size() / 2;
+    leaves.push_back({K_G2, Bytes(c.v.begin(), c.v.begin() + h)});
+    leaves.push_back({K_G2, Bytes(c.v.begin() + h, c.v.end())});
+  }
+  template <class T> void vec(const std::vector<T>& xs) {
+    len(xs.size());
+    for (const T& x : xs) put(x);
+  }
+  void mat(const Matrix<Fr>& m) {
+    len(m.size());
+    for (const auto& row : m) vec(row);
+  }
+  Bytes run(const Ctx& cx, bool compressed) const {
+    Bytes enc[4];
+    size_t pos[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; k++) {
+      Bytes in;
+      size_t n = 0;
+      for (const Leaf& l : leaves)
+        if (l.k == k) {
+          in.insert(in.end(), l.v.begin(), l.v.end());
+          n++;
+        }
+      if (!n) continue;
+      enc[k].resize(n * wire_size(cx, (Kind)k, compressed));
+      int rc = k == K_G1   ? gs_wire_encode_g1(cx.c, n, compressed, in.data(), enc[k].data())
+               : k == K_G2 ? gs_wire_encode_g2(cx.c, n, compressed, in.data(), enc[k].data())
+               : k == K_FR ? gs_wire_encode_fr(cx.c, n, in.data(), enc[k].data())
+                           : gs_wire_encode_gt(cx.c, n, in.data(), enc[k].data());
+      cx.chk(rc);
+    }
+    Bytes out;
+    for (const Leaf& l : leaves) {
+      if (l.k == K_RAW) {
+        out.insert(out.end(), l.v.begin(), l.v.end());
+      } else {
+        size_t w = wire_size(cx, l.k, compressed);
+        out.insert(out.end(), enc[l.k].begin() + pos[l.k], enc[l.k].begin() + pos[l.k] + w);
+        pos[l.k] += w;
+      }
+    }
+    return out;
+  }
+};
+
+struct Reader {
+  struct H {
+    Kind k;
+    size_t i;
+  };
+  const Bytes& b;
+  const Ctx& cx;
+  bool compressed;
+  size_t o = 0;
+  Bytes req[4], val[4];
+  size_t cnt[4] = {0, 0, 0, 0};
+  Reader(const Bytes& data, const Ctx& c, bool comp) : b(data), cx(c), compressed(comp) {}
+  const uint8_t* take(size_t n) {
+    if (o + n > b.size()) throw SerializationError("InvalidData: truncated input");
+    const uint8_t* p = b.data() + o;
+    o += n;
+    return p;
+  }
+  size_t len() {
+    const uint8_t* p = take(8);
+    uint64_t n = 0;
+    for (int i = 0; i < 8; i++) n |= (uint64_t)p[i] << (8 * i);
+    if (n > b.size()) throw SerializationError("InvalidData: length prefix exceeds the input");
+    return (size_t)n;
+  }
+  uint8_t u8() { return *take(1); }
+  H elem(Kind k) {
+    size_t w = wire_size(cx, k, compressed);
+    const uint8_t* p = take(w);
+    req[k].insert(req[k].end(), p, p + w);
+    return {k, cnt[k]++};
+  }
+  std::vector<H> vec(Kind k, size_t per = 1) {
+    size_t n = len();
+    std::vector<H> hs;
+    for (size_t i = 0; i < n * per; i++) hs.push_back(elem(k));
+    return hs;
+  }
+  Matrix<H> mat() {
+    size_t n = len();
+    Matrix<H> m(n);
+    for (auto& row : m) row = vec(K_FR);
+    return m;
+  }
+  void finish(bool validate = true) {
+    if (o != b.size()) throw SerializationError("InvalidData: trailing bytes");
+    for (int k = 0; k < 4; k++) {
+      if (!cnt[k]) continue;
+      val[k].resize(cnt[k] * elem_size(cx, (Kind)k));
+      Bytes ok(cnt[k]);
+      int rc = k == K_G1   ? gs_wire_decode_g1(cx.c, cnt[k], compressed, validate, req[k].data(), val[k].data(), ok.data())
+               : k == K_G2 ? gs_wire_decode_g2(cx.c, cnt[k], compressed, validate, req[k].data(), val[k].data(), ok.data())
+               : k == K_FR ? gs_wire_decode_fr(cx.c, cnt[k], req[k].data(), val[k].data(), ok.data())
+                           : gs_wire_decode_gt(cx.c, cnt[k], validate, req[k].data(), val[k].data(), ok.data());
+      cx.chk(rc);
+      for (uint8_t f : ok)
+        if (!f) throw SerializationError("InvalidData: element rejected");
+    }
+  }
+  Bytes get(H h) const {
+    size_t e = elem_size(cx, h.k);
+    return Bytes(val[h.k].begin() + h.i * e, val[h.k].begin() + (h.i + 1) * e);
+  }
+  template <class Com> std::vector<Com> coms(const std::vector<H>& hs) const {
+    std::vector<Com> out;
+    for (size_t i = 0; i + 1 < hs.size(); i += 2) {
+      Bytes a = get(hs[i]), c = get(hs[i + 1]);
+      a.insert(a.end(), c.begin(), c.end());
+      out.push_back(Com{a});
+    }
+    return out;
+  }
+  template <class T> std::vector<T> vals(const std::vector<H>& hs) const {
+    std::vector<T> out;
+    for (const H& h : hs) out.push_back(T{get(h)});
+    return out;
+  }
+  Matrix<Fr> frs(const Matrix<H>& m) const {
+    Matrix<Fr> out;
+    for (const auto& row : m) out.push_back(vals<Fr>(row));
+    return out;
+  }
+};
+template <class T> struct KindOf;
+template <> struct KindOf<G1Affine> { static constexpr Kind K = K_G1; };
+template <> struct KindOf<G2Affine> { static constexpr Kind K = K_G2; };
+template <> struct KindOf<Fr> { static constexpr Kind K = K_FR; };
+template <> struct KindOf<GT> { static constexpr Kind K = K_GT; };
+
+inline void describe(Writer& w, const Commit1& c) { w.vec(c.coms); w.mat(c.rand); }
+inline void describe(Writer& w, const Commit2& c) { w.vec(c.coms); w.mat(c.rand); }
+inline void describe(Writer& w, const EquProof& p) {
+  w.vec(p.pi);
+  w.vec(p.theta);
+  w.raw(Bytes{(uint8_t)p.equ_type});
+  w.mat(p.rand);
+}
+inline void describe(Writer& w, const CRS& c) {
+  w.vec(c.u);
+  w.vec(c.v);
+  w.put(c.g1_gen);
+  w.put(c.g2_gen);
+  w.put(c.gt_gen);
+}
+template <class A1, class A2, class AT, EquType TY> void describe(Writer& w, const Equation<A1, A2, AT, TY>& e) {
+  w.vec(e.a_consts);
+  w.vec(e.b_consts);
+  w.mat(e.gamma);
+  w.put(e.target);
+}
+
+template <class T> struct Parse;
+template <> struct Parse<Commit1> {
+  static Commit1 run(Reader& r) {
+    auto c = r.vec(K_G1, 2);
+    auto m = r.mat();
+    r.finish();
+    return Commit1{r.coms<Com1>(c), r.frs(m)};
+  }
+};
+template <> struct Parse<Commit2> {
+  static Commit2 run(Reader& r) {
+    auto c = r.vec(K_G2, 2);
+    auto m = r.mat();
+    r.finish();
+    return Commit2{r.coms<Com2>(c), r.frs(m)};
+  }
+};
+template <> struct Parse<EquProof> {
+  static EquProof run(Reader& r) {
+    auto pi = r.vec(K_G2, 2);
+    auto th = r.vec(K_G1, 2);
+    uint8_t ty = r.u8();
+    if (ty > 3) throw SerializationError("InvalidData: EquType");
+    auto m = r.mat();
+    r.finish();
+    return EquProof{r.coms<Com2>(pi), r.coms<Com1>(th), (EquType)ty, r.frs(m)};
+  }
+};
+template <class A1, class A2, class AT, EquType TY> struct Parse<Equation<A1, A2, AT, TY>> {
+  static Equation<A1, A2, AT, TY> run(Reader& r) {
+    auto a = r.vec(KindOf<A1>::K);
+    auto b = r.vec(KindOf<A2>::K);
+    auto g = r.mat();
+    auto t = r.elem(KindOf<AT>::K);
+    r.finish();
+    Equation<A1, A2, AT, TY> e;
+    e.a_consts = r.vals<A1>(a);
+    e.b_consts = r.vals<A2>(b);
+    e.gamma = r.frs(g);
+    e.target = AT{r.get(t)};
+    return e;
+  }
+};
+}  // namespace wire
+
+template <class T> Bytes serialize_compressed(const T& x, const CRS& crs) {
+  wire::Writer w;
+  wire::describe(w, x);
+  return w.run(*crs.ctx, true);
+}
+template <class T> Bytes serialize_uncompressed(const T& x, const CRS& crs) {
+  wire::Writer w;
+  wire::describe(w, x);
+  return w.run(*crs.ctx, false);
+}
+template <class T> T deserialize_compressed(const Bytes& b, const CRS& crs) {
+  wire::Reader r(b, *crs.ctx, true);
+  return wire::Parse<T>::run(r);
+}
+template <class T> T deserialize_uncompressed(const Bytes& b, const CRS& crs) {
+  wire::Reader r(b, *crs.ctx, false);
+  return wire::Parse<T>::run(r);
+}
+// the CRS itself has no context to borrow: it is decoded on a fresh one (curve, device), then installed
+inline CRS deserialize_crs(const Bytes& b, bool compressed, int curve = GS_CURVE_BLS12_381, int device = 0) {
+  Ctx tmp(curve, device);
+  wire::Reader r(b, tmp, compressed);
+  auto u = r.vec(wire::K_G1, 2);
+  auto v = r.vec(wire::K_G2, 2);
+  auto g1 = r.elem(wire::K_G1);
+  auto g2 = r.elem(wire::K_G2);
+  auto gt = r.elem(wire::K_GT);
+  r.finish();
+  if (u.size() != 4 || v.size() != 4) throw SerializationError("InvalidData: the SXDH CRS has two keys per group");
+  return CRS(r.coms<Com1>(u), r.coms<Com2>(v), G1Affine{r.get(g1)}, G2Affine{r.get(g2)}, GT{r.get(gt)}, curve, device);
+}
 
 }  // namespace gs_amd

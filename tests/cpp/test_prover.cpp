@@ -3,6 +3,8 @@
 // Input: a case blob written by tests/test_gpu_cpp_host.py from tests/golden/*.json:
 //   u32 curve, type, m, n; then length-prefixed (u64) sections
 //   u0 u1 v0 v1 g1 g2 gt X Y A B Gamma target R S T xcoms ycoms pi theta
+//   + wire-format expectations from oracle/gs_wire_oracle.py: Commit1 (compressed), EquProof (compressed),
+//     the equation (uncompressed), the CRS (compressed)
 // Exit code 0 and "OK <checks>" on success.
 #include <cstdio>
 #include <cstdlib>
@@ -50,7 +52,8 @@ static Bytes section(std::ifstream& f) {
 template <class A1, class A2, class AT, EquType TY>
 static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const Bytes& Y, const Bytes& A, const Bytes& B,
                 const Bytes& G, const Bytes& tgt, const Bytes& R, const Bytes& S, const Bytes& T, const Bytes& xc,
-                const Bytes& yc, const Bytes& pi, const Bytes& th) {
+                const Bytes& yc, const Bytes& pi, const Bytes& th, const Bytes& w_xcoms, const Bytes& w_proof,
+                const Bytes& w_equ, const Bytes& w_crs, int curve) {
   using Equ = Equation<A1, A2, AT, TY>;
   size_t fr = crs.ctx->sz[1];
   Equ equ;
@@ -112,6 +115,43 @@ static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const By
     CHECK(acc2 == ycoms);
   }
 
+  // wire format (statement.rs:215-390, commit.rs:300-340, prove.rs:600-640: round trips; bytes = the oracle's)
+  {
+    CHECK(serialize_compressed(proof.xcoms, crs) == w_xcoms);
+    CHECK(serialize_compressed(proof.equ_proofs[0], crs) == w_proof);
+    CHECK(serialize_uncompressed(equ, crs) == w_equ);
+    CHECK(serialize_compressed(crs, crs) == w_crs);
+    Commit1 xc2 = deserialize_compressed<Commit1>(w_xcoms, crs);
+    CHECK(xc2 == proof.xcoms);
+    Commit2 yc2 = deserialize_uncompressed<Commit2>(serialize_uncompressed(proof.ycoms, crs), crs);
+    CHECK(yc2 == proof.ycoms);
+    EquProof pf2 = deserialize_compressed<EquProof>(w_proof, crs);
+    CHECK(pf2.equ_type == TY && cat(pf2.pi) == pi && cat(pf2.theta) == th && cat(pf2.rand) == T);
+    Equ equ2 = deserialize_uncompressed<Equ>(w_equ, crs);
+    CHECK(serialize_uncompressed(equ2, crs) == w_equ);
+    CRS crs2 = deserialize_crs(w_crs, true, curve);
+    CHECK(equ2.verify(CProof{xc2, yc2, {pf2}}, crs2));
+    bool threw = false;
+    try {
+      Bytes bad = w_proof;
+      bad.pop_back();
+      deserialize_compressed<EquProof>(bad, crs);
+    } catch (const SerializationError&) {
+      threw = true;
+    }
+    CHECK(threw);
+    threw = false;
+    try {
+      Bytes bad = w_xcoms;
+      // first point of the first commitment: BLS12-381 loses its compression flag, BN254 gets both flags at once
+      if (curve == GS_CURVE_BLS12_381) bad[8] &= 0x7F; else bad[8 + crs.ctx->sz[0] - 1] = 0xFF;
+      deserialize_compressed<Commit1>(bad, crs);
+    } catch (const SerializationError&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
   // negatives: a tampered proof element, commitment and target must be rejected
   {
     CProof bad = proof;
@@ -156,11 +196,12 @@ int main(int argc, char** argv) {
   std::ifstream f(argv[1], std::ios::binary);
   uint32_t hdr[4];
   f.read((char*)hdr, 16);
-  Bytes s[20];
+  Bytes s[24];
   for (auto& b : s) b = section(f);
   CRS crs({Com1{s[0]}, Com1{s[1]}}, {Com2{s[2]}, Com2{s[3]}}, G1Affine{s[4]}, G2Affine{s[5]}, GT{s[6]}, (int)hdr[0]);
   uint32_t ty = hdr[1], m = hdr[2], n = hdr[3];
-#define ARGS crs, m, n, s[7], s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15], s[16], s[17], s[18], s[19]
+#define ARGS crs, m, n, s[7], s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15], s[16], s[17], s[18], s[19], s[20], \
+             s[21], s[22], s[23], (int)hdr[0]
   switch (ty) {
     case 0: run<G1Affine, G2Affine, GT, EquType::PairingProduct>(ARGS); break;
     case 1: run<G1Affine, Fr, G1Affine, EquType::MultiScalarG1>(ARGS); break;

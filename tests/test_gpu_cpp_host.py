@@ -6,10 +6,14 @@ import os
 import struct
 import subprocess
 
+import sys
+
 import numpy as np
 import pytest
 
 from gsutil import HERE, REPO, curve
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
 
 BUILD = os.path.join(HERE, "cpp", "_build")
 LIBDIR = os.path.join(REPO, "groth_sahai_rs_amd", "lib")
@@ -39,11 +43,41 @@ def write_case(c, case, path):
             tgt.tobytes(), c.fr_mat(case["R"]).tobytes(), c.fr_mat(case["S"]).tobytes(), c.fr_mat(case["T"]).tobytes(),
             cat([c.com1(v) for v in case["xcoms"]]), cat([c.com2(v) for v in case["ycoms"]]),
             cat([c.com2(v) for v in case["pi"]]), cat([c.com1(v) for v in case["theta"]])]
+    secs += wire_expectations(c, case)
     with open(path, "wb") as f:
         f.write(struct.pack("<4I", c.curve_id, ty, case["m"], case["n"]))
         for s in secs:
             f.write(struct.pack("<Q", len(s)))
             f.write(s)
+
+
+def wire_expectations(c, case):
+    """Commit1 (compressed), EquProof (compressed), equation (uncompressed), CRS (compressed) from the oracle."""
+    import gs_oracle as O
+    import gs_wire_oracle as W
+
+    O.set_curve(O._bls12_381() if c.name == "bls12_381" else O._bn254())
+    ty = case["type"]
+
+    def pt(h, g):
+        if h is None:
+            return None
+        return (int(h[0], 16), int(h[1], 16)) if g == 1 else ((int(h[0], 16), int(h[1], 16)), (int(h[2], 16), int(h[3], 16)))
+
+    fr = lambda s: int(s, 16)
+    mat = lambda m: [[fr(s) for s in row] for row in m]
+    com = lambda v, g: (pt(v[0], g), pt(v[1], g))
+    gx, gy = ty in (0, 1), ty in (0, 2)
+    a = [pt(v, 1) if gx else fr(v) for v in case["a"]]
+    b = [pt(v, 2) if gy else fr(v) for v in case["b"]]
+    tgt = {0: lambda t: O.f12_unflat([fr(s) for s in t]), 1: lambda t: pt(t, 1), 2: lambda t: pt(t, 2), 3: fr}[ty](
+        case["target"])
+    g = c.golden["crs"]
+    ocrs = {"u": [com(v, 1) for v in g["u"]], "v": [com(v, 2) for v in g["v"]], "g1": pt(g["g1"], 1),
+            "g2": pt(g["g2"], 2), "gt": O.f12_unflat([fr(s) for s in g["gt"]])}
+    return [W.enc_commit([com(v, 1) for v in case["xcoms"]], mat(case["R"]), 1, True),
+            W.enc_equ_proof([com(v, 2) for v in case["pi"]], [com(v, 1) for v in case["theta"]], ty, mat(case["T"]), True),
+            W.enc_equation(ty, a, b, mat(case["gamma"]), tgt, False), W.enc_crs(ocrs, True)]
 
 
 def test_cpp_host_layer_builds():
