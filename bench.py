@@ -133,11 +133,20 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # GS_BENCH_BACKEND=gloo is a REHEARSAL switch for a one-GPU box (ranks share cuda:0, collectives on the
+        # CPU): it exercises the launch contract and the rank logic, its numbers mean nothing
+        backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local)
     dev = "cuda:%d" % local
+    coll_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
     N = 1 << args.log2n
 
     eng = gs.Engine(args.curve, local)
@@ -153,7 +162,7 @@ def main():
     wl = wls[0]
     from groth_sahai_rs_amd.dist import allgather_accumulators
 
-    def one_step():
+    def one_step(collective=True):
         for w in wls:
             w.prove()
         if args.mode == "exact":
@@ -163,7 +172,7 @@ def main():
         accs = [w.verify_rlc() for w in wls]
         allacc = []
         for a in accs:  # cross-GPU product of GT accumulators: all-gather (RCCL) + fixed-order local product
-            allacc += allgather_accumulators(a)
+            allacc += allgather_accumulators(a.to(coll_dev)) if collective else [a]
         pairs = torch.cat(allacc).cpu().numpy()
         return eng.gt_finalize(pairs)
 
@@ -184,7 +193,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -205,7 +214,7 @@ def main():
     if rank == 0:
         eng.prof_enable(True)
         eng.prof_reset()
-        one_step()
+        one_step(collective=False)  # rank 0 alone: no collective inside the profiled step
         eng.sync()
         prof = eng.prof_get()
         eng.prof_enable(False)

@@ -99,3 +99,23 @@ def test_full_config1_batch_properties():
     ok = wl.ok.cpu().numpy()
     assert len(bad) == 4 and [int(v) for v in ok] == [0 if i in bad else 1 for i in range(4096)]
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["exact", "rlc"])
+def test_bench_two_rank_rehearsal(mode):
+    """bench.py under the driver's launch line with 2 ranks.  On a one-GPU box the ranks share cuda:0 and use gloo
+    (GS_BENCH_BACKEND): this checks the launch contract, the per-rank seeds/shards, the barrier + max-over-ranks
+    timing and -- in rlc mode -- the accumulator all-gather; the numbers themselves mean nothing."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, GS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533" if mode == "exact" else "29534", os.path.join(REPO, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--log2n", "8", "--no-cpu", "--mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(2 * 256 / (line["ms_per_step"] / 1e3), rel=1e-6)
+    assert line["roofline"]["alu"]["frac"] > 0
