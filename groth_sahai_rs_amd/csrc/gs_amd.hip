@@ -57,6 +57,7 @@ struct gs_ctx {
   uint64_t work_hint = 0;  // consumed by the next launch() while profiling
   // SIMD slots of the device (CUs x 4); every heavy kernel runs one 512-VGPR wave per SIMD
   size_t simd_slots = 1024;
+  int miller_ch = 0;  // 0 = by batch size (pick_ch); GS_MILLER_CH overrides (experiments)
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
 };
 
@@ -92,6 +93,13 @@ static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
   int rc = ensure(c, b, bytes);
   *out = b.p;
   return rc;
+}
+
+// (P, Q) pairs per Miller lane: every lane squares its own accumulator, so longer lanes do less total work
+// (3 -> 4 pairs: -8 %) but a small batch needs the shorter ones to fill the chip (2^12: 3 pairs = 900 waves)
+static int pick_ch(const gs_ctx* c, size_t N) {
+  if (c->miller_ch > 0) return c->miller_ch > MILLER_CH ? MILLER_CH : c->miller_ch;
+  return N >= 16384 ? 4 : 3;
 }
 
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
@@ -610,7 +618,7 @@ template <class C> struct Impl {
               yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm, (S*)pool));
     // triples per Miller lane: fewer, longer lanes amortise the accumulator squarings once the chip is full
     bool twin = N >= 32768;
-    build_verify(vp, ty, m, n, pm, MILLER_CH, twin, pick_tm(N, m, 2 * n));
+    build_verify(vp, ty, m, n, pm, pick_ch(c, N), twin, pick_tm(N, m, 2 * n));
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
@@ -844,11 +852,12 @@ template <class C> struct Impl {
       if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 0, 2 * iW + 1, 1, 4, 0);
     }
     std::vector<MillerTask> mt;
-    for (size_t s0 = 0; s0 < pr.size(); s0 += MILLER_CH) {
+    const size_t rch = (size_t)pick_ch(c, N);
+    for (size_t s0 = 0; s0 < pr.size(); s0 += rch) {
       MillerTask t;
       memset(&t, 0, sizeof t);
       t.single = 1;
-      t.np = (uint8_t)((pr.size() - s0) < (size_t)MILLER_CH ? (pr.size() - s0) : MILLER_CH);
+      t.np = (uint8_t)((pr.size() - s0) < rch ? (pr.size() - s0) : rch);
       for (int q = 0; q < t.np; q++) t.pr[q] = pr[s0 + q];
       mt.push_back(t);
     }
@@ -1109,6 +1118,7 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
     c->simd_slots = 4 * (size_t)cus;
   if (const char* e = getenv("GS_COOP_FE")) c->coop_fe = atoi(e);
+  if (const char* e = getenv("GS_MILLER_CH")) c->miller_ch = atoi(e);
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return GS_ERR_DEVICE;
