@@ -57,7 +57,8 @@ struct gs_ctx {
   uint64_t work_hint = 0;  // consumed by the next launch() while profiling
   // SIMD slots of the device (CUs x 4); every heavy kernel runs one 512-VGPR wave per SIMD
   size_t simd_slots = 1024;
-  int miller_ch = 0;  // 0 = by batch size (pick_ch); GS_MILLER_CH overrides (experiments)
+  int var_tm = 0;  // 0 = planned (pick_tm); GS_VAR_TM overrides
+  int miller_ch = 0, miller_twin = -1;  // 0 / -1 = planned per batch (miller_cost); GS_MILLER_CH / GS_MILLER_TWIN override
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
 };
 
@@ -95,11 +96,34 @@ static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
   return rc;
 }
 
-// (P, Q) pairs per Miller lane: every lane squares its own accumulator, so longer lanes do less total work
-// (3 -> 4 pairs: -8 %) but a small batch needs the shorter ones to fill the chip (2^12: 3 pairs = 900 waves)
-static int pick_ch(const gs_ctx* c, size_t N) {
-  if (c->miller_ch > 0) return c->miller_ch > MILLER_CH ? MILLER_CH : c->miller_ch;
-  return N >= 16384 ? 4 : 3;
+// ---- Miller-lane planning --------------------------------------------------------------------------
+// A Miller lane carries `np` (P, Q) pairs (twin: (Q, P0, P1) triples with two accumulators) and squares its own
+// accumulator every iteration, so longer lanes do less total work but a small batch needs many short ones to fill the
+// chip.  Cost model (checked against measurements at 2^12..2^16): rounds of waves over the SIMD
+// slots x the longest lane of a wave, in Fq multiplications (profiles/r1/fq_mul_counts.json).
+static void chunk_tasks(std::vector<MillerTask>& mt, const std::vector<PairRef>& pr, int ch, int b, bool single) {
+  size_t P = pr.size();
+  if (P == 0) return;
+  size_t nt = (P + ch - 1) / ch, base = P / nt, rem = P % nt, s0 = 0;  // balanced chunks: sizes differ by <= 1
+  for (size_t t = 0; t < nt; t++) {
+    MillerTask mtk;
+    memset(&mtk, 0, sizeof mtk);
+    mtk.b = (uint8_t)b;
+    mtk.single = single ? 1 : 0;
+    mtk.np = (uint8_t)(base + (t < rem ? 1 : 0));
+    for (int q = 0; q < mtk.np; q++) mtk.pr[q] = pr[s0 + q];
+    s0 += mtk.np;
+    mt.push_back(mtk);
+  }
+}
+static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTask>& mt, bool twin) {
+  int maxnp = 0;
+  for (const MillerTask& t : mt) maxnp = t.np > maxnp ? t.np : maxnp;
+  double lane = twin ? 4536.0 + 7545.0 * maxnp : 2268.0 + 4621.0 * maxnp;
+  double waves = (double)N * mt.size() / 64.0;
+  double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
+  if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);  // whole rounds matter while there are few of them
+  return rounds * lane;
 }
 
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
@@ -213,8 +237,11 @@ static RedTask mkred(int b0, int e0, int b1, int e1, int out_arr, int out_idx) {
 // Append the variable-base terms of ONE output point: chunks of <= tm terms share a lane
 // (and one partial slot); with tm == 1 every term is its own lane/slot.
 static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& slot) {
-  for (size_t s0 = 0; s0 < terms.size(); s0 += sp.tm) {
-    size_t n = terms.size() - s0 < (size_t)sp.tm ? terms.size() - s0 : (size_t)sp.tm;
+  size_t T = terms.size();
+  if (T == 0) return;
+  size_t tm = sp.tm < 1 ? 1 : (size_t)sp.tm, ng = (T + tm - 1) / tm, base = T / ng, rem = T % ng, s0 = 0;
+  for (size_t k = 0; k < ng; k++) {  // balanced groups: sizes differ by <= 1
+    size_t n = base + (k < rem ? 1 : 0);
     GrpTask g;
     g.first = (uint32_t)sp.var.size();
     g.nt = (uint32_t)n;
@@ -225,20 +252,35 @@ static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& 
       v.slot = (uint32_t)slot;
       sp.var.push_back(v);
     }
+    s0 += n;
     sp.grp.push_back(g);
     slot++;
   }
 }
-// terms per lane for a side with `terms_per_output` variable terms per output and `outputs` outputs
-// per equation: the largest of {8, 4, 1} that still leaves >= 48k lanes
-static int pick_tm(size_t N, int terms_per_output, int outputs) {
-  for (int tm : {8, 4}) {
-    if (terms_per_output < 2) break;
-    if (tm == 8 && terms_per_output <= 4) continue;  // the 4-term instantiation carries smaller tables
-    int chunks = (terms_per_output + tm - 1) / tm;
-    if (N * (size_t)chunks * outputs >= 49152) return tm;
+// Variable-base terms per lane (joint Straus MSM, shared doubling chain) for a side with `T` terms per output
+// and `outputs` outputs per equation.  Same cost model as miller_cost: rounds of waves x lane length, lane(nt) =
+// D + P nt Fq multiplications (fits of profiles/r1/fq_mul_counts.json: endomorphism curves G1 808 + 1078 nt,
+// G2 983 + 3073 nt; BN254 G1 1764 + 1014 nt, G2 3780 + 2765 nt).
+static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
+  if (T < 2) return 1;
+  bool endo = c->curve == 0;
+  double D = g2 ? (endo ? 983 : 3780) : (endo ? 808 : 1764), P = g2 ? (endo ? 3073 : 2765) : (endo ? 1078 : 1014);
+  int best_tm = 1;
+  double best = -1;
+  for (int tm = 1; tm <= 8; tm++) {
+    if (c->var_tm > 0 && tm != c->var_tm) continue;
+    int ng = (T + tm - 1) / tm, eff = (T + ng - 1) / ng;
+    if (eff != tm && c->var_tm <= 0) continue;  // the balanced size is what runs; skip aliases
+    double waves = (double)N * outputs * ng / 64.0;
+    double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
+    if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);
+    double cost = rounds * (D + P * eff);
+    if (best < 0 || cost < best) {
+      best = cost;
+      best_tm = eff;
+    }
   }
-  return 1;
+  return best_tm;
 }
 
 // Build the plan of one side.
@@ -416,7 +458,7 @@ template <class C> struct Impl {
     // G1 side: xcoms (m) + theta (ky).  constants A (len n) multiply S; Phi multiplies X; fixed part T.
     {
       SidePlan sp;
-      sp.tm = xg ? pick_tm(N, m + n, ky) : 1;
+      sp.tm = xg ? pick_tm(c, N, m + n, ky, false) : 1;
       build_side(sp, xcoms != nullptr, m, n, xg, kx, ky, pm.RC, pm.XC, pm.SC, pm.PHI, pm.TC, pm.SIG);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -437,7 +479,7 @@ template <class C> struct Impl {
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
     {
       SidePlan sp;
-      sp.tm = yg ? pick_tm(N, m + n, kx) : 1;
+      sp.tm = yg ? pick_tm(c, N, m + n, kx, true) : 1;
       build_side(sp, ycoms != nullptr, n, m, yg, ky, kx, pm.SC, pm.YC, pm.RC, pm.PSI, pm.OM, pm.RHO);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -574,15 +616,7 @@ template <class C> struct Impl {
       for (int l = 0; l < ky; l++) add_pair(pr, 3, 2 * l + a, 1, 2, 2 * l + b);     // (-theta_l.a, v_l.b)
       if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 2, 4 + a, 1, 4, 0);               // (-W1.a, t)
       int lo = (int)vp.mt.size();
-      for (size_t s = 0; s < pr.size(); s += ch) {
-        MillerTask t;
-        memset(&t, 0, sizeof t);
-        t.b = (uint8_t)b;
-        t.single = twin ? 0 : 1;
-        t.np = (uint8_t)((pr.size() - s) < (size_t)ch ? (pr.size() - s) : ch);
-        for (int q = 0; q < t.np; q++) t.pr[q] = pr[s + q];
-        vp.mt.push_back(t);
-      }
+      chunk_tasks(vp.mt, pr, ch, b, !twin);
       int hi = (int)vp.mt.size();
       if (twin) {
         for (int aa = 0; aa < 2; aa++) {
@@ -616,9 +650,27 @@ template <class C> struct Impl {
     RC(scratch(c, "verify.pool", N * pm.total * sizeof(S), &pool));
     RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, (const S*)G, xg ? nullptr : (const S*)A,
               yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm, (S*)pool));
-    // triples per Miller lane: fewer, longer lanes amortise the accumulator squarings once the chip is full
-    bool twin = N >= 32768;
-    build_verify(vp, ty, m, n, pm, pick_ch(c, N), twin, pick_tm(N, m, 2 * n));
+    // lane shape for this batch size: single or twin accumulators, pairs per lane (cost model above)
+    bool twin = false;
+    int ch = 3;
+    {
+      double best = -1;
+      for (int tw = 0; tw < 2; tw++) {
+        if (c->miller_twin >= 0 && tw != c->miller_twin) continue;
+        for (int cand = 2; cand <= MILLER_CH; cand++) {
+          if (c->miller_ch > 0 && cand != c->miller_ch) continue;
+          VerifyPlan tmp;
+          build_verify(tmp, ty, m, n, pm, cand, tw != 0, 1);
+          double cost = miller_cost(c, N, tmp.mt, tw != 0);
+          if (best < 0 || cost < best) {
+            best = cost;
+            twin = tw != 0;
+            ch = cand;
+          }
+        }
+      }
+    }
+    build_verify(vp, ty, m, n, pm, ch, twin, pick_tm(c, N, m, 2 * n, false));
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
@@ -852,14 +904,18 @@ template <class C> struct Impl {
       if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 0, 2 * iW + 1, 1, 4, 0);
     }
     std::vector<MillerTask> mt;
-    const size_t rch = (size_t)pick_ch(c, N);
-    for (size_t s0 = 0; s0 < pr.size(); s0 += rch) {
-      MillerTask t;
-      memset(&t, 0, sizeof t);
-      t.single = 1;
-      t.np = (uint8_t)((pr.size() - s0) < rch ? (pr.size() - s0) : rch);
-      for (int q = 0; q < t.np; q++) t.pr[q] = pr[s0 + q];
-      mt.push_back(t);
+    {
+      double best = -1;
+      for (int cand = 2; cand <= MILLER_CH; cand++) {
+        if (c->miller_ch > 0 && cand != c->miller_ch) continue;
+        std::vector<MillerTask> tmp;
+        chunk_tasks(tmp, pr, cand, 0, true);
+        double cost = miller_cost(c, N, tmp, false);
+        if (best < 0 || cost < best) {
+          best = cost;
+          mt = tmp;
+        }
+      }
     }
     const MillerTask* dmt;
     RC(upload(c, "rlc.mt", mt, &dmt));
@@ -1119,6 +1175,8 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
     c->simd_slots = 4 * (size_t)cus;
   if (const char* e = getenv("GS_COOP_FE")) c->coop_fe = atoi(e);
   if (const char* e = getenv("GS_MILLER_CH")) c->miller_ch = atoi(e);
+  if (const char* e = getenv("GS_MILLER_TWIN")) c->miller_twin = atoi(e);
+  if (const char* e = getenv("GS_VAR_TM")) c->var_tm = atoi(e);
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return GS_ERR_DEVICE;
