@@ -227,3 +227,45 @@ def test_reference_algebraic_properties(engines, cname):
     assert all((cells[i] == one).all() for i in range(4))
     cells = e.pairing_sum(0, np.zeros(0, np.uint8), np.zeros(0, np.uint8))
     assert all((cells[i] == one).all() for i in range(4))
+
+
+def test_status_codes_and_empty_batches(engines):
+    """The boundary's error behaviour (include/gs_amd.h): status codes where the reference panics (shape asserts,
+    prove.rs:106-113) or cannot happen in Rust (null pointers, missing CRS); an empty batch is a no-op."""
+    import ctypes
+
+    import groth_sahai_rs_amd as gs
+    from groth_sahai_rs_amd.capi import GsError
+
+    c, e = engines["bls12_381"]
+    lib = e.lib
+    z = ctypes.c_void_p(0)
+    one = np.zeros(1 << 16, dtype=np.uint8)
+    p = ctypes.c_void_p(one.ctypes.data)
+    n0 = ctypes.c_size_t(0)
+    n1 = ctypes.c_size_t(1)
+    # empty batch: OK without touching any pointer
+    assert lib.gs_prove_batch(e.ctx, 0, n0, 4, 4, z, z, z, z, z, z, z, z, z, z, z, z) == 0
+    assert lib.gs_verify_batch(e.ctx, 0, n0, 4, 4, z, z, z, z, z, z, z, z, z) == 0
+    # shape errors (the reference panics on empty variable lists, prove.rs:108)
+    for m, n in ((0, 1), (1, 0), (-1, 2)):
+        assert lib.gs_prove_batch(e.ctx, 0, n1, m, n, p, p, p, p, p, p, p, p, z, z, p, p) == 1  # GS_ERR_SHAPE
+    assert lib.gs_prove_batch(e.ctx, 7, n1, 1, 1, p, p, p, p, p, p, p, p, z, z, p, p) in (1, 3)  # unknown type
+    assert b"" != lib.gs_last_error(e.ctx)
+    # null pointer for a required array
+    assert lib.gs_prove_batch(e.ctx, 0, n1, 1, 1, z, p, p, p, p, p, p, p, z, z, p, p) == 3  # GS_ERR_ARG
+    assert lib.gs_verify_batch(e.ctx, 0, n1, 1, 1, p, p, p, p, p, p, p, p, z) == 3
+    # a context without a CRS refuses to prove / verify but still offers the CRS-free hooks
+    fresh = gs.Engine(0, 0)
+    assert lib.gs_prove_batch(fresh.ctx, 0, n1, 1, 1, p, p, p, p, p, p, p, p, z, z, p, p) == 4  # GS_ERR_NOCRS
+    with pytest.raises(GsError):
+        fresh.verify_batch(0, 1, 1, 1, one[:96], one[:192], one[:32], one[:576], one[:192], one[:384], one[:768],
+                           one[:384])
+    g1 = c.g1(c.golden["g1_smul"][0]["out"])
+    out = fresh.g_mul_batch(1, g1.reshape(1, -1), c.fr(2).reshape(1, -1))
+    assert c.g1_dec(out.reshape(-1).view(np.uint64)) == c.golden["g1_smul"][1]["out"]
+    fresh.close()
+    # bad curve / device ids
+    h = ctypes.c_void_p()
+    assert lib.gs_ctx_create(5, 0, ctypes.byref(h)) == 3
+    assert lib.gs_ctx_create(0, 99, ctypes.byref(h)) == 2  # GS_ERR_DEVICE
