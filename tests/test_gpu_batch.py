@@ -119,3 +119,73 @@ def test_bench_two_rank_rehearsal(mode):
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
     assert line["value"] == pytest.approx(2 * 256 / (line["ms_per_step"] / 1e3), rel=1e-6)
     assert line["roofline"]["alu"]["frac"] > 0
+
+
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])
+@pytest.mark.parametrize("ty", [0, 1, 2, 3])
+def test_edge_values_against_c_oracle(cname, cid, ty):
+    """Degenerate inputs the reference accepts silently: identity witnesses / constants, zero and r-1 scalars, zero
+    Gamma rows, no randomness at all, repeated points.  Outputs must still equal the C restatement bit for bit and
+    the verdicts (true or false -- the targets are no longer satisfied) must agree."""
+    import torch
+
+    import groth_sahai_rs_amd as gs
+    import gs_ref_py as ref
+    from groth_sahai_rs_amd.workload import CURVES, Workload
+
+    eng = gs.Engine(cid, 0)
+    m, n, N = 3, 2, 8
+    wl = Workload(eng, ty=ty, N=N, m=m, n=n, seed=4242 + ty, corrupt_every=0)
+    sh = wl.sh
+    kx, ky, sx, sy, st = sh["kx"], sh["ky"], sh["sx"], sh["sy"], sh["st"]
+    r = CURVES[cid]["r"]
+    mont = lambda v: torch.from_numpy(np.array([(v * (1 << 256) % r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)],
+                                               dtype=np.uint64).view(np.uint8).copy()).to(wl.X.device)
+
+    def put(t, e, per_eq, idx, size, val):  # element idx of equation e in a flat uint8 tensor
+        o = e * per_eq * size + idx * size
+        t[o:o + size] = val
+
+    zero = lambda size: torch.zeros(size, dtype=torch.uint8, device=wl.X.device)
+    rm1 = mont(r - 1)
+    # e0: first X is the identity / zero scalar, first Gamma row zero
+    put(wl.X, 0, m, 0, sx, zero(sx))
+    for j in range(n):
+        put(wl.Gamma, 0, m * n, j, 32, zero(32))
+    # e1: first Y and first A are identity / zero, every B is identity / zero
+    put(wl.Y, 1, n, 0, sy, zero(sy))
+    put(wl.A, 1, n, 0, sx, zero(sx))
+    for i in range(m):
+        put(wl.B, 1, m, i, sy, zero(sy))
+    # e2: no randomness at all
+    wl.R[2 * m * kx * 32:3 * m * kx * 32] = 0
+    wl.S[2 * n * ky * 32:3 * n * ky * 32] = 0
+    wl.T[2 * ky * kx * 32:3 * ky * kx * 32] = 0
+    # e3: Gamma = 0 and the commit randomness of X is r-1 everywhere
+    wl.Gamma[3 * m * n * 32:4 * m * n * 32] = 0
+    for i in range(m * kx):
+        put(wl.R, 3, m * kx, i, 32, rm1)
+    # e4: repeated variables / constants, Gamma of ones and r-1
+    put(wl.X, 4, m, 1, sx, wl.X[4 * m * sx:4 * m * sx + sx].clone())
+    put(wl.B, 4, m, 1, sy, wl.B[4 * m * sy:4 * m * sy + sy].clone())
+    for k in range(m * n):
+        put(wl.Gamma, 4, m * n, k, 32, mont(1) if k % 2 else rm1)
+    wl.prove()
+    wl.verify()
+    eng.sync()
+    host = lambda t: t.cpu().numpy()
+    X, Y, A, B, G, R, S, T = map(host, (wl.X, wl.Y, wl.A, wl.B, wl.Gamma, wl.R, wl.S, wl.T))
+    xc, yc, pi, th, tgt, ok = map(host, (wl.xcoms, wl.ycoms, wl.pi, wl.theta, wl.target, wl.ok))
+    cut = lambda a, e, sz: a[e * sz:(e + 1) * sz]
+    for e in range(6):  # 0..4 patched, 5 untouched
+        out = ref.commit_and_prove(cname, ty, m, n, cut(X, e, m * sx), cut(Y, e, n * sy), cut(A, e, n * sx),
+                                   cut(B, e, m * sy), cut(G, e, m * n * 32), cut(R, e, m * kx * 32),
+                                   cut(S, e, n * ky * 32), cut(T, e, ky * kx * 32), wl.crs)
+        for name, got, per in (("xcoms", xc, m * eng.COM1), ("ycoms", yc, n * eng.COM2), ("pi", pi, kx * eng.COM2),
+                               ("theta", th, ky * eng.COM1)):
+            assert (out[name] == cut(got, e, per)).all(), (ty, e, name)
+        want = ref.verify(cname, ty, m, n, cut(A, e, n * sx), cut(B, e, m * sy), cut(G, e, m * n * 32), cut(tgt, e, st),
+                          out["xcoms"], out["ycoms"], out["pi"], out["theta"], wl.crs)
+        assert int(ok[e]) == want, (ty, e, "verdict")
+    assert int(ok[5]) == 1 and int(ok[2]) == 1  # untouched / randomness-free proofs of true statements still verify
+    eng.close()
