@@ -26,21 +26,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def host_cores():
+    """CPUs this process may actually use: hardware threads, capped by the affinity mask and by the cgroup CPU
+    quota (the one-GPU box shows 256 hardware threads but grants 16 CPUs of time)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, os.cpu_count() or 1
+
+
 def cpu_baseline(sample_units, threads):
-    """Time the C restatement of the reference path on `sample_units` PPE 4x4 units."""
+    """Time the C restatement of the reference path on `sample_units` PPE 4x4 units (all granted cores), and on two
+    units with one thread (the reference's own single-equation bench shape, BASELINE configs[0])."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
         import gs_ref_py
     except Exception as ex:  # oracle not built
         return {"value": None, "unit": "proofs+verifies/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % ex}
+    t1, u1, ok1 = gs_ref_py.bench_ppe(2, 4, 4, 1)
     t, units, ok = gs_ref_py.bench_ppe(sample_units, 4, 4, threads)
     return {
         "value": units / t,
         "unit": "proofs+verifies/s",
         "cores": threads,
         "kind": "port",
+        "single_thread": u1 / t1,
+        "hardware_threads_visible": os.cpu_count(),
         "sample": "%d PPE 4x4 commit_and_prove+verify units, reference evaluation order (5 pairing_sums, "
-        "per-op normalisation), %d threads over equations, all verified=%s, %.1f s" % (units, threads, ok, t),
+        "per-op normalisation), %d threads over equations (= the CPUs granted to this process), all verified=%s, "
+        "%.1f s; single thread: %.2f units/s" % (units, threads, ok and ok1, t, u1 / t1),
     }
 
 
@@ -276,8 +307,8 @@ def main():
     if rank == 0:
         res["roofline"] = roof
         if not args.no_cpu:
-            threads = os.cpu_count() or 1
-            sample = args.cpu_sample or max(8 * threads, 64)   # ~10-30 s of CPU work on the box's host cores
+            threads, _ = host_cores()
+            sample = args.cpu_sample or max(128 * threads, 256)   # ~10-30 s of CPU work on the granted host cores
             res["cpu_baseline"] = cpu_baseline(sample, threads)
         print(json.dumps(res))
     if dist is not None:
