@@ -41,6 +41,7 @@ template <class C> struct FqM {
   GS_HD static uint32_t r2(int i) { return C::P_R2[i]; }
 };
 template <class C> struct FrM {
+  typedef C Curve;
   static constexpr int N = C::NR;
   static constexpr int BITS = C::Q_BITS;
   static constexpr uint32_t INV = C::Q_INV;
