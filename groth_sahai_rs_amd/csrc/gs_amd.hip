@@ -129,7 +129,9 @@ static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTas
   double waves = (double)N * mt.size() / 64.0;
   double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
   if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);  // whole rounds matter while there are few of them
-  return rounds * lane;
+  // + the k_final lane that multiplies a cell's partials together (54 Fq multiplications each; large arities)
+  double per_cell = (double)mt.size() * (twin ? 2.0 : 1.0) / 4.0;
+  return rounds * lane + per_cell * 54.0;
 }
 
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
@@ -166,6 +168,8 @@ static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, 
 // ---------------------------------------------------------------------------
 // shape helpers
 // ---------------------------------------------------------------------------
+// scalar preparation goes one-lane-per-output once an equation carries this many Gamma entries
+static inline bool wide_prep(int m, int n) { return (long)m * n >= 1024; }
 static inline bool x_is_group(int ty) { return ty == GS_PPE || ty == GS_MSMEG1; }
 static inline bool y_is_group(int ty) { return ty == GS_PPE || ty == GS_MSMEG2; }
 
@@ -281,7 +285,8 @@ static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
     double waves = (double)N * outputs * ng / 64.0;
     double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
     if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);
-    double cost = rounds * (D + P * eff);
+    // + the lane of k_red that folds the ng partial sums of an output (matters for large arities)
+    double cost = rounds * (D + P * eff) + (double)ng * (g2 ? 29.0 + 14.0 : 16.0);
     if (best < 0 || cost < best) {
       best = cost;
       best_tm = eff;
@@ -473,9 +478,20 @@ template <class C> struct Impl {
     PoolMap pm = prove_pool(m, n, kx, ky);
     void* pool;
     RC(scratch(c, "prove.pool", N * pm.total * sizeof(S), &pool));
-    RC(launch(c, "k_prep_prove", k_prep_prove<C>, N, 64, N, m, n, kx, ky, (const S*)G, (const S*)R, (const S*)Sm,
-              (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
-              yg ? nullptr : (const S*)B, pm, (S*)pool));
+    if (wide_prep(m, n)) {  // large arity: one lane per output scalar
+      int W = m * kx + n * ky + ky * kx + m + n + kx * n + ky * m;
+      RC(launch(c, "k_prep_prove.a", k_prep_prove_wide_a<C>, N * (size_t)W, 64, N * (size_t)W, W, m, n, kx, ky,
+                (const S*)G, (const S*)R, (const S*)Sm, (const S*)T, xg ? nullptr : (const S*)X,
+                yg ? nullptr : (const S*)Y, pm, (S*)pool));
+      size_t tb = N * (size_t)(kx * ky + kx + ky);
+      RC(launch(c, "k_prep_prove.b", k_prep_prove_wide_b<C>, tb, 64, tb, m, n, kx, ky, (const S*)R, (const S*)Sm,
+                (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
+                yg ? nullptr : (const S*)B, pm, (S*)pool));
+    } else {
+      RC(launch(c, "k_prep_prove", k_prep_prove<C>, N, 64, N, m, n, kx, ky, (const S*)G, (const S*)R, (const S*)Sm,
+                (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
+                yg ? nullptr : (const S*)B, pm, (S*)pool));
+    }
     // small batches: G1 side on the context's stream, G2 side on side[0], each side's variable-base kernel on a
     // further stream; everything joins back before this function returns
     struct CurGuard {
@@ -690,8 +706,13 @@ template <class C> struct Impl {
     pm.total = o;
     void* pool;
     RC(scratch(c, "verify.pool", N * pm.total * sizeof(S), &pool));
-    RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, (const S*)G, xg ? nullptr : (const S*)A,
-              yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm, (S*)pool));
+    const bool wide = wide_prep(m, n);
+    if (wide)
+      RC(launch(c, "k_fr_canonical", k_fr_canonical<C>, N * (size_t)m * n, 64, N * (size_t)m * n, m * n, (const S*)G,
+                pm.total, (S*)pool + pm.GC));
+    RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, wide ? nullptr : (const S*)G,
+              xg ? nullptr : (const S*)A, yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm,
+              (S*)pool));
     // lane shape for this batch size: single or twin accumulators, pairs per lane (cost model above)
     bool twin = false;
     int ch = 3;
@@ -838,8 +859,13 @@ template <class C> struct Impl {
     pm.total = o;
     void* pool;
     RC(scratch(c, "rlc.pool", N * pm.total * sizeof(S), &pool));
-    RC(launch(c, "k_prep_verify_rlc", k_prep_verify_rlc<C>, N, 64, N, m, n, (const S*)G, xg ? nullptr : (const S*)A,
-              yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, rho, pm, (S*)pool));
+    const bool wide = wide_prep(m, n);
+    if (wide)
+      RC(launch(c, "k_fr_canonical", k_fr_canonical<C>, N * (size_t)m * n, 64, N * (size_t)m * n, m * n, (const S*)G,
+                pm.total, (S*)pool + pm.GC));
+    RC(launch(c, "k_prep_verify_rlc", k_prep_verify_rlc<C>, N, 64, N, m, n, wide ? nullptr : (const S*)G,
+              xg ? nullptr : (const S*)A, yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, rho,
+              pm, (S*)pool));
     auto RH = [&](int a, int b) { return pm.RH + 2 * a + b; };
     // ---- pass 1
     int n1 = m + ky;

@@ -209,6 +209,97 @@ __global__ void __launch_bounds__(64, GS_WPE)
   }
 }
 
+// The same for large arities (m n in the thousands and beyond, benches/bench.rs:451-498 uses 334 x 334): one lane per
+// OUTPUT SCALAR instead of one per equation.  Phase a: conversions and the two matrix products (a lane = one entry
+// of Psi or Phi = one inner product); phase b: the <= 8 scalars per equation that depend on Psi / Phi.
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE)
+    k_prep_prove_wide_a(size_t total, int W, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R,
+                        const Fr<C>* S, const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, PoolMap pm, Fr<C>* pool) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / W;
+  int w = (int)(g % W);
+  typedef Fr<C> S_;
+  G += e * m * n;
+  R += e * m * kx;
+  S += e * n * ky;
+  T += e * ky * kx;
+  S_* P = pool + e * pm.total;
+  int o = 0;
+  if (w < o + m * kx) { P[pm.RC + w - o] = from_mont(R[w - o]); return; }
+  o += m * kx;
+  if (w < o + n * ky) { P[pm.SC + w - o] = from_mont(S[w - o]); return; }
+  o += n * ky;
+  if (w < o + ky * kx) { P[pm.TC + w - o] = from_mont(T[w - o]); return; }
+  o += ky * kx;
+  if (w < o + m) { if (xs) P[pm.XC + w - o] = from_mont(xs[e * m + w - o]); return; }
+  o += m;
+  if (w < o + n) { if (ys) P[pm.YC + w - o] = from_mont(ys[e * n + w - o]); return; }
+  o += n;
+  if (w < o + kx * n) {  // Psi[k][j] = sum_i R[i][k] G[i][j]
+    int k = (w - o) / n, j = (w - o) % n;
+    S_ psi = fzero<FrM<C>>();
+    for (int i = 0; i < m; i++) psi = add(psi, mul(R[i * kx + k], G[i * n + j]));
+    P[pm.PSI + k * n + j] = from_mont(psi);
+    return;
+  }
+  o += kx * n;
+  if (w < o + ky * m) {  // Phi[l][i] = sum_j S[j][l] G[i][j]
+    int l = (w - o) / m, i = (w - o) % m;
+    S_ phi = fzero<FrM<C>>();
+    for (int j = 0; j < n; j++) phi = add(phi, mul(S[j * ky + l], G[i * n + j]));
+    P[pm.PHI + l * m + i] = from_mont(phi);
+  }
+}
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE)
+    k_prep_prove_wide_b(size_t total, int m, int n, int kx, int ky, const Fr<C>* R, const Fr<C>* S, const Fr<C>* T,
+                        const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm, Fr<C>* pool) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const int W = kx * ky + kx + ky;
+  size_t e = g / W;
+  int w = (int)(g % W);
+  typedef Fr<C> S_;
+  R += e * m * kx;
+  S += e * n * ky;
+  T += e * ky * kx;
+  S_* P = pool + e * pm.total;
+  if (w < kx * ky) {  // Omega[k][l] = sum_j Psi[k][j] S[j][l] - T[l][k]
+    int k = w / ky, l = w % ky;
+    S_ om = fzero<FrM<C>>();
+    for (int j = 0; j < n; j++) om = add(om, mul(to_mont(P[pm.PSI + k * n + j]), S[j * ky + l]));
+    P[pm.OM + k * ky + l] = from_mont(sub(om, T[l * kx + k]));
+  } else if (w < kx * ky + kx) {  // rho_k = sum_j Psi[k][j] y_j + sum_i R[i][k] b_i   (scalar-Y types)
+    int k = w - kx * ky;
+    if (!bs) return;
+    S_ rho = fzero<FrM<C>>();
+    if (ys)
+      for (int j = 0; j < n; j++) rho = add(rho, mul(to_mont(P[pm.PSI + k * n + j]), ys[e * n + j]));
+    for (int i = 0; i < m; i++) rho = add(rho, mul(R[i * kx + k], bs[e * m + i]));
+    P[pm.RHO + k] = from_mont(rho);
+  } else {  // sigma_l = sum_i Phi[l][i] x_i + sum_j S[j][l] a_j   (scalar-X types)
+    int l = w - kx * ky - kx;
+    if (!as) return;
+    S_ sig = fzero<FrM<C>>();
+    if (xs)
+      for (int i = 0; i < m; i++) sig = add(sig, mul(to_mont(P[pm.PHI + l * m + i]), xs[e * m + i]));
+    for (int j = 0; j < n; j++) sig = add(sig, mul(S[j * ky + l], as[e * n + j]));
+    P[pm.SIG + l] = from_mont(sig);
+  }
+}
+// out[e * out_stride + i] = canonical(in[e * cnt + i]): the Gamma conversion of the verifier, one lane per scalar
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE)
+    k_fr_canonical(size_t total, int cnt, const Fr<C>* in, int out_stride, Fr<C>* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / cnt;
+  int i = (int)(g % cnt);
+  out[e * out_stride + i] = from_mont(in[g]);
+}
+
 // Fr preparation for verify: Gamma (and scalar constants / target) -> canonical
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE) k_prep_verify(size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as,
@@ -216,7 +307,8 @@ __global__ void __launch_bounds__(64, GS_WPE) k_prep_verify(size_t N, int m, int
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   Fr<C>* P = pool + e * pm.total;
-  for (int i = 0; i < m * n; i++) P[pm.GC + i] = from_mont(G[e * m * n + i]);
+  if (G)  // (large arities convert Gamma with k_fr_canonical, one lane per scalar)
+    for (int i = 0; i < m * n; i++) P[pm.GC + i] = from_mont(G[e * m * n + i]);
   if (as)
     for (int j = 0; j < n; j++) P[pm.AC + j] = from_mont(as[e * n + j]);
   if (bs)
@@ -251,7 +343,8 @@ __global__ void __launch_bounds__(64, GS_WPE)
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   Fr<C>* P = pool + e * pm.total;
-  for (int i = 0; i < m * n; i++) P[pm.GC + i] = from_mont(G[e * m * n + i]);
+  if (G)
+    for (int i = 0; i < m * n; i++) P[pm.GC + i] = from_mont(G[e * m * n + i]);
   if (bs)
     for (int i = 0; i < m; i++) P[pm.BC + i] = from_mont(bs[e * m + i]);
   Fr<C> rm[4];

@@ -80,6 +80,13 @@ def test_large_arity_ppe():
     _run(0, "bls12_381", 0, 2, 40, 33, [1])
 
 
+@pytest.mark.parametrize("ty", [1, 2, 3])
+def test_large_arity_scalar_types(ty):
+    """33 x 32 (>= 1024 Gamma entries): the one-lane-per-output-scalar preparation kernels (k_prep_prove_wide_a/b,
+    k_fr_canonical) for the equation types whose rho / sigma scalars depend on Psi / Phi."""
+    _run(0, "bls12_381", ty, 2, 33, 32, [0, 1])
+
+
 def test_bn254_batch():
     _run(1, "bn254", 0, 128, 4, 4, [0, 77])
     _run(1, "bn254", 1, 64, 3, 2, [5])
