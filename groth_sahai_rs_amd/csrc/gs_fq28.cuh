@@ -258,7 +258,43 @@ template <class C> GS_HD Fq28<C> mul(const Fq28<C>& a, const Fq28<C>& b) {
   for (int i = 0; i < C::L; i++) r.v[i] = rv[i];
   return r;
 }
-template <class C> GS_HD Fq28<C> sqr(const Fq28<C>& a) { return mul(a, a); }
+// squaring: its own out-of-line body on the device (L(L+1)/2 product mads against the doubled operand instead of
+// L^2, and one operand to marshal instead of two); same result and contract as mul(a, a)
+template <class C> GS_HD_NOINLINE i32x16 sqr28_vec(i32x16 a) {
+  int32_t av[C::L], dv[C::L], rv[C::L];
+#pragma unroll
+  for (int i = 0; i < C::L; i++) {
+    av[i] = a[i];
+    dv[i] = a[i] * 2;
+  }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM)
+  if constexpr (C::L == 14)
+    sqr28_asm_14<C>(rv, av, dv);
+  else
+    sqr28_asm_10<C>(rv, av, dv);
+#else
+  (void)dv;
+  mul28_generic<C, int32_t>(rv, av, av);
+#endif
+  i32x16 r = 0;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r[i] = rv[i];
+  return r;
+}
+template <class C> GS_HD Fq28<C> sqr(const Fq28<C>& a) {
+#if defined(GS_FQ28_CHECK)
+  return mul(a, a);
+#else
+  i32x16 av = 0;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) av[i] = a.v[i];
+  i32x16 rv = sqr28_vec<C>(av);
+  Fq28<C> r;
+#pragma unroll
+  for (int i = 0; i < C::L; i++) r.v[i] = rv[i];
+  return r;
+#endif
+}
 
 // ---- tests modulo p --------------------------------------------------------------
 // robust a == 0 (mod p) for any lazily reduced a within the mul contract: one

@@ -94,7 +94,7 @@ template <class C> GS_HD Fp2<C> inv(const Fp2<C>& a) {
 
 // generic helpers for code templated on F = Fq or Fp2
 template <class C> GS_HD Fq<C> mul_l2(const Fq<C>& a, const Fq<C>& b) { return mul(a, b); }  // 2*2 <= 8
-template <class C> GS_HD Fq<C> sqr_l2(const Fq<C>& a) { return mul(a, a); }
+template <class C> GS_HD Fq<C> sqr_l2(const Fq<C>& a) { return sqr(a); }
 
 template <class F> GS_HD F zero_of();
 template <class F> GS_HD F one_of();
