@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # every symbol include/gs_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "gs_ctx_create", "gs_ctx_destroy", "gs_set_stream", "gs_sync", "gs_last_error", "gs_version", "gs_sizes",
-    "gs_set_crs", "gs_crs_generate",
+    "gs_set_crs", "gs_crs_generate", "gs_crs_generate_hiding",
     "gs_commit_g1_dev", "gs_commit_g2_dev", "gs_commit_fr_b1_dev", "gs_commit_fr_b2_dev",
     "gs_commit_g1", "gs_commit_g2", "gs_commit_fr_b1", "gs_commit_fr_b2",
     "gs_prove_batch_dev", "gs_prove_batch", "gs_verify_batch_dev", "gs_verify_batch",
@@ -120,11 +120,13 @@ class Engine:
         self._crs = crs
         self._chk(self.lib.gs_set_crs(self.ctx, _p(crs)))
 
-    def crs_generate(self, p1, p2, scalars):
-        """CRS bytes of the reference's shape from generators p1, p2 and scalars (a1, a2, t1, t2)."""
+    def crs_generate(self, p1, p2, scalars, hiding=False):
+        """CRS bytes of the reference's shape from generators p1, p2 and scalars (a1, a2, t1, t2); hiding=True gives
+        the simulation key of generator.rs:65-77."""
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         out = self._out(self.CRS)
-        self._chk(self.lib.gs_crs_generate(self.ctx, _p(u8(p1)), _p(u8(p2)), _p(u8(scalars)), _p(out)))
+        fn = self.lib.gs_crs_generate_hiding if hiding else self.lib.gs_crs_generate
+        self._chk(fn(self.ctx, _p(u8(p1)), _p(u8(p2)), _p(u8(scalars)), _p(out)))
         return out
 
     # -- shapes ---------------------------------------------------------------

@@ -1321,6 +1321,51 @@ int gs_crs_generate(gs_ctx* c, const void* p1, const void* p2, const void* sc, v
   return gs_multi_pairing_batch(c, 1, 1, p1, p2, o);
 }
 
+// The simulation ("hiding") key of generator.rs:65-77: identical except v = t*q - generator, so that commitments are
+// perfectly hiding.  t*q - p is one left_mul with the row (t, -1) over the column ((q, q), (p, p)).
+int gs_crs_generate_hiding(gs_ctx* c, const void* p1, const void* p2, const void* sc, void* out) {
+  RC(gs_crs_generate(c, p1, p2, sc, out));
+  size_t fq = sz_fq(c->curve), g1 = 2 * fq, g2 = 4 * fq;
+  const uint8_t* s = (const uint8_t*)sc;
+  uint8_t* o = (uint8_t*)out;
+  // Montgomery form of -1: r - (2^256 mod r)
+  uint32_t m1[8];
+  {
+    uint64_t br = 0;
+    for (int i = 0; i < 8; i++) {
+      uint32_t rw = c->curve == 0 ? Bls12_381::R_WORDS[i] : Bn254::R_WORDS[i];
+      uint32_t ow = c->curve == 0 ? Bls12_381::Q_ONE[i] : Bn254::Q_ONE[i];
+      uint64_t x = (uint64_t)rw - ow - br;
+      m1[i] = (uint32_t)x;
+      br = (x >> 63) & 1;
+    }
+  }
+  std::vector<uint8_t> lhs(2 * SZ_FR), col, res;
+  memcpy(lhs.data() + SZ_FR, m1, SZ_FR);
+  // G1: out layout u0 = (p1, q1), u1 = (t1 p1, v1)
+  memcpy(lhs.data(), s + 2 * SZ_FR, SZ_FR);
+  col.assign(4 * g1, 0);
+  res.assign(2 * g1, 0);
+  memcpy(col.data(), o + g1, g1);           // (q1, q1)
+  memcpy(col.data() + g1, o + g1, g1);
+  memcpy(col.data() + 2 * g1, p1, g1);      // (p1, p1)
+  memcpy(col.data() + 3 * g1, p1, g1);
+  RC(gs_mat_left_mul_com1(c, 1, 2, lhs.data(), col.data(), res.data()));
+  memcpy(o + 3 * g1, res.data(), g1);
+  // G2: v0 = (p2, q2), v1 = (t2 p2, v2) after the 4 G1 points
+  uint8_t* o2 = o + 4 * g1;
+  memcpy(lhs.data(), s + 3 * SZ_FR, SZ_FR);
+  col.assign(4 * g2, 0);
+  res.assign(2 * g2, 0);
+  memcpy(col.data(), o2 + g2, g2);
+  memcpy(col.data() + g2, o2 + g2, g2);
+  memcpy(col.data() + 2 * g2, p2, g2);
+  memcpy(col.data() + 3 * g2, p2, g2);
+  RC(gs_mat_left_mul_com2(c, 1, 2, lhs.data(), col.data(), res.data()));
+  memcpy(o2 + 3 * g2, res.data(), g2);
+  return GS_OK;
+}
+
 // ---- commit ------------------------------------------------------------------
 #define COMMIT_DEV(NAME, FT, GROUP, TAB, TAG)                                                              \
   int NAME(gs_ctx* c, size_t n, const void* v, const void* r, void* out) {                                 \

@@ -38,13 +38,13 @@ class CRS:
         self.engine.set_crs(flat)
 
 
-def generate_crs(p1, p2, rng, curve=0, device=0):
+def generate_crs(p1, p2, rng, curve=0, device=0, hiding=False):
     """AbstractCrs::generate_crs (generator.rs:81-118) with the group generators supplied by the caller
     (the reference draws them with G1::rand / G2::rand, which has no counterpart outside arkworks);
     the four scalars a1, a2, t1, t2 are drawn from `rng` in the reference's order (generator.rs:90-93)."""
     eng = Engine(curve, device)
     sc = np.concatenate([rng.fr() for _ in range(4)])
-    raw = eng.crs_generate(p1, p2, sc).view(np.uint64)
+    raw = eng.crs_generate(p1, p2, sc, hiding=hiding).view(np.uint64)  # hiding: generator.rs:65-77
     eng.close()
     g1, g2 = eng.G1 // 8, eng.G2 // 8
     o = 0

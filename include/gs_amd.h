@@ -78,6 +78,9 @@ int gs_set_crs(gs_ctx* ctx, const void* crs_host);
  *   u = [(p1, a1 p1), (t1 p1, t1 a1 p1)],  v = [(p2, a2 p2), (t2 p2, t2 a2 p2)],  g1 = p1, g2 = p2, gt = e(p1, p2).
  * Host pointers; the result is written to crs_out (CRS layout) and NOT installed (call gs_set_crs). */
 int gs_crs_generate(gs_ctx* ctx, const void* p1_g1, const void* p2_g2, const void* scalars_fr4, void* crs_out);
+/* The simulation ("hiding") key of src/generator.rs:65-77 (dead code there): as above with
+ *   u[1] = (t1 p1, t1 a1 p1 - p1),  v[1] = (t2 p2, t2 a2 p2 - p2). */
+int gs_crs_generate_hiding(gs_ctx* ctx, const void* p1_g1, const void* p2_g2, const void* scalars_fr4, void* crs_out);
 
 /* ---- commit (src/prover/commit.rs) -------------------------------------- */
 /* c_i = iota1(X_i) + r_i0 u0 + r_i1 u1   (commit.rs:78-100; N=1 is commit_G1 :59-75) */

@@ -156,3 +156,36 @@ def test_generate_crs_structure(setup):
     # scope here (targets depend on the CRS); a commit with it must simply run
     com = mirror.batch_commit_G1([crs.g1_gen], crs, type("R", (), {"fr": lambda self: c.fr(5)})())
     assert len(com.coms) == 1 and com.coms[0].any()
+
+
+def test_generate_hiding_crs(setup):
+    """generator.rs:65-77 (the simulation key): u[1].1 = t1 * u[0].1 - g1, v[1].1 = t2 * v[0].1 - g2; everything else
+    as in the binding key.  Checked against the big-integer oracle."""
+    import os
+    import sys
+
+    from gsutil import REPO
+
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gs_oracle as O
+
+    c, mirror, _ = setup
+    O.set_curve(O._bls12_381())
+    g = c.golden
+    h1, h2 = g["g1_smul"][4]["out"], g["g2_smul"][5]["out"]
+    p1, p2 = c.g1(h1), c.g2(h2)
+    P1 = (int(h1[0], 16), int(h1[1], 16))
+    P2 = ((int(h2[0], 16), int(h2[1], 16)), (int(h2[2], 16), int(h2[3], 16)))
+    a1, a2, t1, t2 = 0x1234567, 0x7654321, 0xABCDEF01, 0x10FEDCBA
+
+    def rng():
+        q = [c.fr(a1), c.fr(a2), c.fr(t1), c.fr(t2)]
+        return type("R", (), {"fr": lambda self: q.pop(0)})()
+
+    bind, hide = mirror.generate_crs(p1, p2, rng()), mirror.generate_crs(p1, p2, rng(), hiding=True)
+    assert (bind.u[0] == hide.u[0]).all() and (bind.v[0] == hide.v[0]).all() and (bind.gt_gen == hide.gt_gen).all()
+    assert (bind.u[1].reshape(2, -1)[0] == hide.u[1].reshape(2, -1)[0]).all()
+    v1 = O.g1_add(O.g1_mul(t1 * a1, P1), O.g1_neg(P1))
+    v2 = O.g2_add(O.g2_mul(t2 * a2, P2), O.g2_neg(P2))
+    assert c.g1_dec(hide.u[1].reshape(2, -1)[1]) == ["%x" % v1[0], "%x" % v1[1]]
+    assert c.g2_dec(hide.v[1].reshape(2, -1)[1]) == ["%x" % v2[0][0], "%x" % v2[0][1], "%x" % v2[1][0], "%x" % v2[1][1]]
