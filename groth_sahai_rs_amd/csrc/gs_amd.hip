@@ -270,12 +270,11 @@ static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& 
 }
 // Variable-base terms per lane (joint Straus MSM, shared doubling chain) for a side with `T` terms per output
 // and `outputs` outputs per equation.  Same cost model as miller_cost: rounds of waves x lane length, lane(nt) =
-// D + P nt Fq multiplications (fits of profiles/r1/fq_mul_counts.json: endomorphism curves G1 832 + 829 nt,
-// G2 1000 + 2365 nt; BN254 G1 1768 + 772 nt, G2 3864 + 2075 nt).
+// D + P nt Fq multiplications (fits of profiles/r1/fq_mul_counts.json, the same within 3 % on both curves now that
+// both have endomorphism decompositions: G1 832 + 829 nt, G2 1000 + 2365 nt).
 static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
   if (T < 2) return 1;
-  bool endo = c->curve == 0;
-  double D = g2 ? (endo ? 1000 : 3864) : (endo ? 832 : 1768), P = g2 ? (endo ? 2365 : 2075) : (endo ? 829 : 772);
+  double D = g2 ? 1000 : 832, P = g2 ? 2365 : 829;
   int best_tm = 1;
   double best = -1;
   for (int tm = 1; tm <= 8; tm++) {

@@ -302,6 +302,68 @@ template <int NL> GS_HD void recode_w4_limbs(int8_t* dg, const uint32_t* k) {
   }
 }
 
+// ---- lattice decomposition (BN curves: no eigenvalue of size sqrt(r) / r^(1/4) exists, so the sub-scalars come from
+// Babai rounding against a reduced basis B of {v : sum v_j eig^j = 0 mod r}; gen_params.py derives and checks B and
+// G_i = floor(2^256 |(B^-1)_0i|)).  c_i = floor(k G_i / 2^256) (sign GS_i), k_j = [j = 0] k - sum_i c_i B_ij.
+template <int NA, int NB> GS_HD void mp_mul(uint32_t* out, const uint32_t* a, const uint32_t* b) {
+  for (int i = 0; i < NA + NB; i++) out[i] = 0;
+  for (int i = 0; i < NA; i++) {
+    uint64_t carry = 0;
+    for (int j = 0; j < NB; j++) {
+      uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+      out[i + j] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    out[i + NB] = (uint32_t)carry;
+  }
+}
+// acc (W words, two's complement) -= or += a (NA <= W words, non-negative)
+template <int W, int NA> GS_HD void mp_acc(uint32_t* acc, const uint32_t* a, bool add) {
+  uint64_t c = add ? 0 : 1;  // a + (~b + 1) = a - b
+  for (int i = 0; i < W; i++) {
+    uint32_t w = i < NA ? a[i] : 0u;
+    if (!add) w = ~w;
+    uint64_t t = (uint64_t)acc[i] + w + c;
+    acc[i] = (uint32_t)t;
+    c = t >> 32;
+  }
+}
+template <int D, int GW, int BW, int NL>
+GS_HD void endo_lattice(uint32_t (*mag)[NL], uint8_t* sgn, const uint32_t* k, const uint32_t (*G)[GW], const uint8_t* GS,
+                        const uint32_t (*B)[D][BW], const uint8_t (*BS)[D]) {
+  constexpr int W = 10;
+  static_assert(GW + BW < W && NL <= W, "decomposition width");
+  uint32_t c[D][GW];
+  for (int i = 0; i < D; i++) {
+    uint32_t t[8 + GW], g[GW];
+    for (int w = 0; w < GW; w++) g[w] = G[i][w];
+    mp_mul<8, GW>(t, k, g);
+    for (int w = 0; w < GW; w++) c[i][w] = t[8 + w];
+  }
+  for (int j = 0; j < D; j++) {
+    uint32_t acc[W];
+    for (int w = 0; w < W; w++) acc[w] = (j == 0 && w < 8) ? k[w] : 0u;
+    for (int i = 0; i < D; i++) {
+      uint32_t t[GW + BW], b[BW];
+      for (int w = 0; w < BW; w++) b[w] = B[i][j][w];
+      mp_mul<GW, BW>(t, c[i], b);
+      bool neg_prod = (GS[i] != 0) != (BS[i][j] != 0);
+      mp_acc<W, GW + BW>(acc, t, neg_prod);  // acc -= (+-) c_i B_ij
+    }
+    bool negative = (acc[W - 1] >> 31) != 0;
+    if (negative) {
+      uint64_t cy = 1;
+      for (int w = 0; w < W; w++) {
+        uint64_t t = (uint64_t)(~acc[w]) + cy;
+        acc[w] = (uint32_t)t;
+        cy = t >> 32;
+      }
+    }
+    sgn[j] = negative ? 1 : 0;
+    for (int w = 0; w < NL; w++) mag[j][w] = acc[w];
+  }
+}
+
 template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fq<C>>& r, const Aff<Fq<C>>& p, const Fr<C>& k) {
   uint32_t kk[8], q[8], k1[4], k2[4], lam[4];
   for (int i = 0; i < 8; i++) kk[i] = k.v[i];
@@ -359,7 +421,14 @@ template <class C> GS_HD void endo_apply(Aff<Fq<C>>& t, int s) {
 }
 template <class C> GS_HD void endo_apply(Aff<Fp2<C>>& t, int s) {
   if (aff_is_inf(t)) return;  // (0, 0) stays the identity flag
-  if (s == 1) {
+  if constexpr (C::IS_BN) {
+    // psi^s on the D-type twist = the twist Frobenius of the Miller loop: conjugate s times, scale by xi^(k (p^s-1)/6)
+    if (s == 0) return;
+    Fp2<C> x = (s & 1) ? conj(t.x) : t.x, y = (s & 1) ? conj(t.y) : t.y;
+    t.x = mul(x, frob_coeff<C>(s, 2));
+    t.y = mul(y, frob_coeff<C>(s, 3));
+    return;
+  } else if (s == 1) {
     t.x = mul(conj(t.x), fp2_const28<C>(C::PSI_X_28));
     t.y = mul(conj(t.y), fp2_const28<C>(C::PSI_Y_28));
   } else if (s == 2) {
@@ -413,9 +482,14 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fp2<C>>& r, const Aff<F
   r.z = mul(r.z, zback);
 }
 
-// dispatch: endomorphism path where the curve has one
+template <class C, class F, int TMAX>
+GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks, int nt);
+// dispatch: endomorphism path where the curve has one (BN curves: the one-term case of the joint routine, whose
+// digit streams come from the lattice decomposition)
 template <class C, class F> GS_HD void jac_smul_any(Jac<F>& r, const Aff<F>& p, const Fr<C>& k) {
-  if constexpr (C::HAS_ENDO)
+  if constexpr (C::HAS_ENDO && C::IS_BN)
+    jac_msm_straus<C, F, 1>(r, &p, &k, 1);
+  else if constexpr (C::HAS_ENDO)
     jac_smul_endo<C>(r, p, k);
   else
     jac_smul(r, p, k);
@@ -427,64 +501,59 @@ template <class C, class F> GS_HD void jac_smul_any(Jac<F>& r, const Aff<F>& p, 
 // sub-scalars), one 8-entry table per base.  Used for the Gamma-weighted inner
 // products once the batch is large enough that fewer, longer lanes still fill the chip.
 // ---------------------------------------------------------------------------
-template <class C> GS_HD void endo_apply(Jac<Fq<C>>& t, int s) {
-  if (s == 1) {
-    Fq<C> beta;
-    for (int i = 0; i < C::L; i++) beta.v[i] = C::BETA_28[i];
-    t.x = mul(t.x, beta);
-  }
-}
-template <class C> GS_HD void endo_apply(Jac<Fp2<C>>& t, int s) {
-  if (s == 1) {
-    t.x = mul(conj(t.x), fp2_const28<C>(C::PSI_X_28));
-    t.y = mul(conj(t.y), fp2_const28<C>(C::PSI_Y_28));
-    t.z = conj(t.z);
-  } else if (s == 2) {
-    Fq<C> nx, ny;
-    for (int l = 0; l < C::L; l++) {
-      nx.v[l] = C::PSI2_X_28[l];
-      ny.v[l] = C::PSI2_Y_28[l];
-    }
-    t.x = mul_fp(t.x, nx);
-    t.y = mul_fp(t.y, ny);
-  } else if (s == 3) {
-    t.x = mul(conj(t.x), fp2_const28<C>(C::PSI3_X_28));
-    t.y = mul(conj(t.y), fp2_const28<C>(C::PSI3_Y_28));
-    t.z = conj(t.z);
-  }
-}
-// sub-scalar digit streams of one term: G1 -> 2 x 33 digits, G2 -> 4 x 17 digits (endo curves)
-template <class C> GS_HD void endo_digits(int8_t* dg, const Fr<C>& k, const Jac<Fq<C>>*) {
-  uint32_t kk[8], q[8], k1[4], k2[4], lam[4];
-  for (int i = 0; i < 8; i++) kk[i] = k.v[i];
-  for (int i = 0; i < 4; i++) lam[i] = C::LAMBDA[i];
-  limb_divmod<8, 4>(q, k1, kk, lam);
-  for (int i = 0; i < 4; i++) k2[i] = q[i];
-  recode_w4_limbs<4>(dg, k1);
-  recode_w4_limbs<4>(dg + 33, k2);
-}
-template <class C> GS_HD void endo_digits(int8_t* dg, const Fr<C>& k, const Jac<Fp2<C>>*) {
-  uint32_t n[8], q[8], xa[2], d[4][2];
-  for (int i = 0; i < 8; i++) n[i] = k.v[i];
-  xa[0] = C::XABS_LIMBS[0];
-  xa[1] = C::XABS_LIMBS[1];
-  for (int j = 0; j < 3; j++) {
-    limb_divmod<8, 2>(q, d[j], n, xa);
-    for (int i = 0; i < 8; i++) n[i] = q[i];
-  }
-  d[3][0] = n[0];
-  d[3][1] = n[1];
-  for (int j = 0; j < 4; j++) recode_w4_limbs<2>(dg + 17 * j, d[j]);
-}
-template <class C, class F> struct EndoShape;  // streams per term, digits per stream, sign pattern
+// Sub-scalar digit streams of one term (signed w = 4 digits, NS streams of ND digits) and the sign of each stream.
+//   BLS12: G1 k = k1 + k2 lambda by division (2 x 33 digits); G2 base-|x| digits with the fixed sign pattern
+//          +Q, -psi Q, +psi^2 Q, -psi^3 Q (4 x 17 digits)
+//   BN   : lattice decomposition, signs per scalar: G1 2 x 41 digits (<= 160-bit slots), G2 4 x 25 (<= 96-bit)
+template <class C, class F> struct EndoShape;
 template <class C> struct EndoShape<C, Fq<C>> {
-  static constexpr int NS = 2, ND = 33;
-  GS_HD static bool flip(int) { return false; }
+  static constexpr int NS = 2, NL = C::IS_BN ? 5 : 4, ND = 8 * NL + 1;
 };
 template <class C> struct EndoShape<C, Fp2<C>> {
-  static constexpr int NS = 4, ND = 17;
-  GS_HD static bool flip(int s) { return (s & 1) != 0; }  // +Q, -psi Q, +psi^2 Q, -psi^3 Q
+  static constexpr int NS = 4, NL = C::IS_BN ? 3 : 2, ND = 8 * NL + 1;
 };
+template <class C> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, const Fr<C>& k, const Jac<Fq<C>>*) {
+  typedef EndoShape<C, Fq<C>> E;
+  uint32_t kk[8];
+  for (int i = 0; i < 8; i++) kk[i] = k.v[i];
+  if constexpr (C::IS_BN) {
+    uint32_t mag[2][E::NL];
+    endo_lattice<2, 5, 4, E::NL>(mag, sgn, kk, C::GLV1_G, C::GLV1_GS, C::GLV1_B, C::GLV1_BS);
+    for (int s = 0; s < 2; s++) recode_w4_limbs<E::NL>(dg + E::ND * s, mag[s]);
+  } else {
+    uint32_t q[8], k1[4], k2[4], lam[4];
+    for (int i = 0; i < 4; i++) lam[i] = C::LAMBDA[i];
+    limb_divmod<8, 4>(q, k1, kk, lam);
+    for (int i = 0; i < 4; i++) k2[i] = q[i];
+    recode_w4_limbs<4>(dg, k1);
+    recode_w4_limbs<4>(dg + E::ND, k2);
+    sgn[0] = sgn[1] = 0;
+  }
+}
+template <class C> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, const Fr<C>& k, const Jac<Fp2<C>>*) {
+  typedef EndoShape<C, Fp2<C>> E;
+  uint32_t n[8];
+  for (int i = 0; i < 8; i++) n[i] = k.v[i];
+  if constexpr (C::IS_BN) {
+    uint32_t mag[4][E::NL];
+    endo_lattice<4, 7, 2, E::NL>(mag, sgn, n, C::GLS2_G, C::GLS2_GS, C::GLS2_B, C::GLS2_BS);
+    for (int s = 0; s < 4; s++) recode_w4_limbs<E::NL>(dg + E::ND * s, mag[s]);
+  } else {
+    uint32_t q[8], xa[2], d[4][2];
+    xa[0] = C::XABS_LIMBS[0];
+    xa[1] = C::XABS_LIMBS[1];
+    for (int j = 0; j < 3; j++) {
+      limb_divmod<8, 2>(q, d[j], n, xa);
+      for (int i = 0; i < 8; i++) n[i] = q[i];
+    }
+    d[3][0] = n[0];
+    d[3][1] = n[1];
+    for (int j = 0; j < 4; j++) {
+      recode_w4_limbs<2>(dg + E::ND * j, d[j]);
+      sgn[j] = (uint8_t)(j & 1);  // x < 0: psi acts as -|x|
+    }
+  }
+}
 
 template <class C, class F, int TMAX>
 GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks, int nt) {
@@ -494,9 +563,10 @@ GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks,
     Aff<F> at[TMAX][8];
     F zback;
     int8_t dg[TMAX][E::NS * E::ND];
+    uint8_t sg[TMAX][E::NS];
     for (int t = 0; t < nt; t++) {
       smul_build_table(tab[t], ps[t]);
-      endo_digits<C>(dg[t], ks[t], (const Jac<F>*)nullptr);
+      endo_digits<C>(dg[t], sg[t], ks[t], (const Jac<F>*)nullptr);
     }
     table_global_z<C>(&at[0][0], &tab[0][0], 8 * nt, zback);  // ONE isomorphic curve for all the terms' tables
     jac_set_inf(r);
@@ -516,7 +586,7 @@ GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks,
           if (a == 0) continue;
           Aff<F> e = at[t][(a < 0 ? -a : a) - 1];
           endo_apply<C>(e, s);
-          if ((a < 0) != E::flip(s)) e.y = neg(e.y);
+          if ((a < 0) != (sg[t][s] != 0)) e.y = neg(e.y);
           jac_madd(r, r, e);
         }
     }

@@ -193,3 +193,31 @@ def test_cooperative_final_exponentiation(twin, cname):
         coop(0, ptr(gt), ptr(out3))
         for j in range(3):
             assert (out3.reshape(3, -1)[j] == want).all(), j
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_endomorphism_scalar_multiplication_random(twin, cname):
+    """GLV / GLS paths (BLS12-381: division by lambda / base-|x| digits; BN254: lattice decomposition with per-scalar
+    signs) on random and extreme scalars against the big-integer oracle, both groups."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gs_oracle as O
+
+    c = curve(cname)
+    oc = O.set_curve(O._bls12_381() if cname == "bls12_381" else O._bn254())
+    rng = np.random.default_rng(99)
+    ks = [0, 1, c.r - 1, c.r - 2, (1 << 128) - 1, 1 << 127, (1 << 64) + 1, c.r // 2]
+    ks += [int.from_bytes(rng.bytes(40), "little") % c.r for _ in range(24)]
+    g1, g2 = c.g1(c.golden["g1_smul"][2]["out"]), c.g2(c.golden["g2_smul"][2]["out"])  # 3 * generator
+    P1, P2 = O.g1_mul(3, oc.g1), O.g2_mul(3, oc.g2)
+    for k in ks:
+        out = np.zeros(2 * c.nq, dtype=np.uint64)
+        getattr(twin, "twin_g1_smul_" + cname)(ptr(g1), ptr(c.fr(k)), ptr(out))
+        want = O.g1_mul(k, P1)
+        assert c.g1_dec(out) == (None if want is None else ["%x" % want[0], "%x" % want[1]]), hex(k)
+        out = np.zeros(4 * c.nq, dtype=np.uint64)
+        getattr(twin, "twin_g2_smul_" + cname)(ptr(g2), ptr(c.fr(k)), ptr(out))
+        want = O.g2_mul(k, P2)
+        assert c.g2_dec(out) == (None if want is None else ["%x" % v for v in (want[0][0], want[0][1], want[1][0], want[1][1])]), hex(k)
