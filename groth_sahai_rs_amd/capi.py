@@ -35,7 +35,8 @@ class GsError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libgs_amd.so")
+    # GS_AMD_LIB: load another build of the same library (A/B measurements); it is still a HIP build, never a fallback
+    return os.environ.get("GS_AMD_LIB") or os.path.join(_HERE, "lib", "libgs_amd.so")
 
 
 _LIB = None

@@ -8,7 +8,9 @@ Product scanning with ONE signed 64-bit accumulator v[32:33]:
     k <  L:    m_k = ((acc & M) * (-p^-1)) & M ; acc += m_k p_0 ; acc >>= 28
     k >= L:    r_(k-L) = acc & M ; acc >>= 28          (last: r_(L-1) = acc)
 No carry-flag instruction anywhere (they are half rate on gfx950); L*L*2 mads
-+ ~5 full-rate ops per column.  m_k lives in the register that later receives
++ ~5 full-rate ops per column.  Every instruction of the block is 8 bytes long and the
+block starts 8-byte aligned (.p2align 3): with the stream at 4 (mod 8) the SAME code ran
+10 % slower end to end (measured; the placement used to flip with unrelated edits).  m_k lives in the register that later receives
 r_k.  v32..v34 are caller-saved scratch VGPRs (the product is out of line).
 Included INSIDE namespace gs by gs_fq28.cuh.
 """
@@ -40,7 +42,7 @@ def gen(L):
             out.append("v_and_b32 %s, 0xfffffff, %s" % (R(k - L), LO))
         out.append("v_ashrrev_i64 %s, 28, %s" % (ACC, ACC))
     out.append("v_mov_b32 %s, %s" % (R(L - 1), LO))
-    body = "\\n\\t".join(out)
+    body = ".p2align 3\\n\\t" + "\\n\\t".join(out)
     outs = ", ".join('"=&v"(r[%d])' % i for i in range(L))
     ins = ", ".join('"v"(a[%d])' % i for i in range(L)) + ", " + ", ".join('"v"(b[%d])' % i for i in range(L))
     ins += ", " + ", ".join('"s"(C::P28[%d])' % i for i in range(L)) + ', "s"(C::P28_INV)'
@@ -82,7 +84,7 @@ def gen_sqr(L):
             out.append("v_and_b32 %s, 0xfffffff, %s" % (R(k - L), LO))
         out.append("v_ashrrev_i64 %s, 28, %s" % (ACC, ACC))
     out.append("v_mov_b32 %s, %s" % (R(L - 1), LO))
-    body = "\\n\\t".join(out)
+    body = ".p2align 3\\n\\t" + "\\n\\t".join(out)
     outs = ", ".join('"=&v"(r[%d])' % i for i in range(L))
     ins = ", ".join('"v"(a[%d])' % i for i in range(L)) + ", " + ", ".join('"v"(d[%d])' % i for i in range(L))
     ins += ", " + ", ".join('"s"(C::P28[%d])' % i for i in range(L)) + ', "s"(C::P28_INV)'

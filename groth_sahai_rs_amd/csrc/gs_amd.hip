@@ -47,6 +47,7 @@ struct gs_ctx {
   DevBuf crs_g2;   // 6 G2 points: v0.0 v0.1 v1.0 v1.1 W2.0 W2.1
   DevBuf tab_g1;   // 5 window tables (u0.0 u0.1 u1.0 u1.1 W1.1)
   DevBuf tab_g2;
+  DevBuf line_tab;  // Miller line tables of the 6 CRS G2 points (k_line_tables)
   // scratch
   std::map<std::string, DevBuf> scratch;
   // profiling
@@ -103,35 +104,82 @@ static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
 }
 
 // ---- Miller-lane planning --------------------------------------------------------------------------
-// A Miller lane carries `np` (P, Q) pairs (twin: (Q, P0, P1) triples with two accumulators) and squares its own
-// accumulator every iteration, so longer lanes do less total work but a small batch needs many short ones to fill the
-// chip.  Cost model (checked against measurements at 2^12..2^16): rounds of waves over the SIMD
-// slots x the longest lane of a wave, in Fq multiplications (profiles/r1/fq_mul_counts.json).
-static void chunk_tasks(std::vector<MillerTask>& mt, const std::vector<PairRef>& pr, int ch, int b, bool single) {
+// A Miller lane carries up to MILLER_CH (P, Q) pairs (twin: (Q, P0, P1) triples with two accumulators) and squares its
+// own accumulator every iteration, so longer lanes do less total work but a small batch needs many short ones to fill
+// the chip.  Pairs whose G2 argument is a CRS element read precomputed lines and are cheaper.  Cost model (checked
+// against measurements at 2^12..2^16): rounds of waves over the SIMD slots x the longest lane, in
+// Fq multiplications (profiles/r1/fq_mul_counts.json).  Lanes are task-major (a wave = 64 equations of ONE task).
+struct MCost {
+  double base, var, fix;
+};
+// (profiles/r1/fq_mul_counts.json: miller*_per_lane, _per_pair / _per_triple, _per_fixed_pair / _per_fixed_triple)
+static inline MCost mcost(int curve, bool twin) {
+  if (curve == 0) return twin ? MCost{4536.0, 7545.0, 5848.0} : MCost{2268.0, 4621.0, 2924.0};
+  return twin ? MCost{4680.0, 9991.0, 7568.0} : MCost{2340.0, 6207.0, 3784.0};
+}
+static bool g_line_tables = true;  // GS_LINE_TABLES=0 disables the table-reading pairs (experiments)
+static inline bool pair_fixed(const PairRef& r) { return g_line_tables && r.q_arr == 2; }  // Q array 2 = CRS (v, W2)
+// Split one cell's pairs into the fewest tasks whose lane cost stays within `budget`: costly pairs first, each to the
+// lightest task that still has room (LPT).
+static void chunk_tasks(std::vector<MillerTask>& mt, const std::vector<PairRef>& pr, double budget, int b, bool single,
+                        const MCost& mc) {
   size_t P = pr.size();
   if (P == 0) return;
-  size_t nt = (P + ch - 1) / ch, base = P / nt, rem = P % nt, s0 = 0;  // balanced chunks: sizes differ by <= 1
-  for (size_t t = 0; t < nt; t++) {
-    MillerTask mtk;
-    memset(&mtk, 0, sizeof mtk);
-    mtk.b = (uint8_t)b;
-    mtk.single = single ? 1 : 0;
-    mtk.np = (uint8_t)(base + (t < rem ? 1 : 0));
-    for (int q = 0; q < mtk.np; q++) mtk.pr[q] = pr[s0 + q];
-    s0 += mtk.np;
-    mt.push_back(mtk);
+  std::vector<size_t> order;
+  for (size_t i = 0; i < P; i++)
+    if (!pair_fixed(pr[i])) order.push_back(i);
+  for (size_t i = 0; i < P; i++)
+    if (pair_fixed(pr[i])) order.push_back(i);
+  for (size_t nt = (P + MILLER_CH - 1) / MILLER_CH; nt <= P; nt++) {
+    std::vector<double> load(nt, 0.0);
+    std::vector<std::vector<size_t>> members(nt);
+    for (size_t idx : order) {
+      size_t best = nt;
+      for (size_t t = 0; t < nt; t++)
+        if (members[t].size() < (size_t)MILLER_CH && (best == nt || load[t] < load[best])) best = t;
+      members[best].push_back(idx);
+      load[best] += pair_fixed(pr[idx]) ? mc.fix : mc.var;
+    }
+    double mx = 0;
+    for (double l : load) mx = l > mx ? l : mx;
+    if (mx > budget && nt < P) continue;
+    for (size_t t = 0; t < nt; t++) {
+      MillerTask mtk;
+      memset(&mtk, 0, sizeof mtk);
+      mtk.b = (uint8_t)b;
+      mtk.single = single ? 1 : 0;
+      mtk.np = (uint8_t)members[t].size();
+      for (int q = 0; q < mtk.np; q++) mtk.pr[q] = pr[members[t][q]];
+      mt.push_back(mtk);
+    }
+    return;
   }
 }
 static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTask>& mt, bool twin) {
-  int maxnp = 0;
-  for (const MillerTask& t : mt) maxnp = t.np > maxnp ? t.np : maxnp;
-  double lane = twin ? 4536.0 + 7545.0 * maxnp : 2268.0 + 4621.0 * maxnp;
-  double waves = (double)N * mt.size() / 64.0;
+  const MCost mc = mcost(c->curve, twin);
+  double lane = 0;
+  for (const MillerTask& t : mt) {
+    double l = mc.base;
+    for (int q = 0; q < t.np; q++) l += pair_fixed(t.pr[q]) ? mc.fix : mc.var;
+    lane = l > lane ? l : lane;
+  }
+  double waves = (double)mt.size() * (double)((N + 63) / 64);
   double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
   if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);  // whole rounds matter while there are few of them
   // + the k_final lane that multiplies a cell's partials together (54 Fq multiplications each; large arities)
   double per_cell = (double)mt.size() * (twin ? 2.0 : 1.0) / 4.0;
   return rounds * lane + per_cell * 54.0;
+}
+// lane-cost budgets worth trying: a variable + f fixed pairs
+static std::vector<double> miller_budgets(const gs_ctx* c, bool twin) {
+  const MCost mc = mcost(c->curve, twin);
+  std::vector<double> out;
+  for (int a = 1; a <= MILLER_CH; a++)
+    for (int f = 0; f <= 2 && a + f <= MILLER_CH; f++) {
+      if (c->miller_ch > 0 && a + f != c->miller_ch) continue;
+      out.push_back(a * mc.var + f * mc.fix);
+    }
+  return out;
 }
 
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
@@ -426,6 +474,9 @@ template <class C> struct Impl {
     HIPCHK(c, hipMemcpy(c->crs_g2.p, g2pts.data(), g2pts.size(), hipMemcpyHostToDevice));
     RC(launch(c, "k_crs_derive.g1", k_crs_derive<C, F1>, 1, 64, (uint8_t*)c->crs_g1.p));
     RC(launch(c, "k_crs_derive.g2", k_crs_derive<C, F2>, 1, 64, (uint8_t*)c->crs_g2.p));
+    // Miller line tables of the six G2 points (v0, v1, W2): the verifier pairs theta / PB against them
+    RC(ensure(c, c->line_tab, 6 * (size_t)miller_line_count<C>() * sizeof(Line<C>)));
+    RC(launch(c, "k_line_tables", k_line_tables<C>, 6, 64, (const uint8_t*)c->crs_g2.p, (Line<C>*)c->line_tab.p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(g1pts.data(), c->crs_g1.p, g1pts.size(), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(g2pts.data(), c->crs_g2.p, g2pts.size(), hipMemcpyDeviceToHost));
@@ -610,7 +661,8 @@ template <class C> struct Impl {
 
   // P arrays: 0 PA scratch, 1 xcoms, 2 crs G1 consts, 3 theta
   // Q arrays: 0 ycoms, 1 B, 2 crs G2 consts, 3 pi, 4 target (MSMEG2)
-  static void build_verify(VerifyPlan& vp, int ty, int m, int n, const PoolMap& pm, int ch, bool twin, int tm) {
+  static void build_verify(VerifyPlan& vp, int curve, int ty, int m, int n, const PoolMap& pm, double budget, bool twin,
+                           int tm) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
     int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     // ---- G1-side points: PA_j.a = map_a_j.a + sum_i Gamma_ij c_i.a ;  PB.a = sum_i b_i c_i.a - lin_t
@@ -673,7 +725,7 @@ template <class C> struct Impl {
       for (int l = 0; l < ky; l++) add_pair(pr, 3, 2 * l + a, 1, 2, 2 * l + b);     // (-theta_l.a, v_l.b)
       if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 2, 4 + a, 1, 4, 0);               // (-W1.a, t)
       int lo = (int)vp.mt.size();
-      chunk_tasks(vp.mt, pr, ch, b, !twin);
+      chunk_tasks(vp.mt, pr, budget, b, !twin, mcost(curve, twin));
       int hi = (int)vp.mt.size();
       if (twin) {
         for (int aa = 0; aa < 2; aa++) {
@@ -712,27 +764,26 @@ template <class C> struct Impl {
     RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, wide ? nullptr : (const S*)G,
               xg ? nullptr : (const S*)A, yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm,
               (S*)pool));
-    // lane shape for this batch size: single or twin accumulators, pairs per lane (cost model above)
+    // lane shape for this batch size: single or twin accumulators, lane-cost budget (cost model above)
     bool twin = false;
-    int ch = 3;
+    double budget = 3 * 4621.0;
     {
       double best = -1;
       for (int tw = 0; tw < 2; tw++) {
         if (c->miller_twin >= 0 && tw != c->miller_twin) continue;
-        for (int cand = 2; cand <= MILLER_CH; cand++) {
-          if (c->miller_ch > 0 && cand != c->miller_ch) continue;
+        for (double cand : miller_budgets(c, tw != 0)) {
           VerifyPlan tmp;
-          build_verify(tmp, ty, m, n, pm, cand, tw != 0, 1);
+          build_verify(tmp, c->curve, ty, m, n, pm, cand, tw != 0, 1);
           double cost = miller_cost(c, N, tmp.mt, tw != 0);
           if (best < 0 || cost < best) {
             best = cost;
             twin = tw != 0;
-            ch = cand;
+            budget = cand;
           }
         }
       }
     }
-    build_verify(vp, ty, m, n, pm, ch, twin, pick_tm(c, N, m, 2 * n, false));
+    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false));
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
@@ -783,14 +834,19 @@ template <class C> struct Impl {
     qarr.base[4] = (const uint8_t*)target;
     qarr.stride[4] = (uint32_t)Z::G2;
     {
-      uint64_t pairs = 0;  // (P, Q) pairs (twin: (Q, P0, P1) triples) per equation
-      for (const MillerTask& t : vp.mt) pairs += t.np;
-      c->work_hint = N * pairs;
+      // (P, Q) pairs (twin: (Q, P0, P1) triples) per equation, a table-reading pair counted at its cost ratio
+      const MCost mc = mcost(c->curve, twin);
+      double pairs = 0;
+      for (const MillerTask& t : vp.mt)
+        for (int q = 0; q < t.np; q++) pairs += pair_fixed(t.pr[q]) ? mc.fix / mc.var : 1.0;
+      c->work_hint = (uint64_t)((double)N * pairs);
     }
     if (twin)
-      RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2));
+      RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
+                (const Line<C>*)(g_line_tables ? c->line_tab.p : nullptr)));
     else
-      RC(launch(c, "k_miller", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2));
+      RC(launch(c, "k_miller", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
+                (const Line<C>*)(g_line_tables ? c->line_tab.p : nullptr)));
     *mpart_out = mpart;
     return GS_OK;
   }
@@ -973,10 +1029,9 @@ template <class C> struct Impl {
     std::vector<MillerTask> mt;
     {
       double best = -1;
-      for (int cand = 2; cand <= MILLER_CH; cand++) {
-        if (c->miller_ch > 0 && cand != c->miller_ch) continue;
+      for (double cand : miller_budgets(c, false)) {
         std::vector<MillerTask> tmp;
-        chunk_tasks(tmp, pr, cand, 0, true);
+        chunk_tasks(tmp, pr, cand, 0, true, mcost(c->curve, false));
         double cost = miller_cost(c, N, tmp, false);
         if (best < 0 || cost < best) {
           best = cost;
@@ -1008,11 +1063,14 @@ template <class C> struct Impl {
     qarr.base[4] = (const uint8_t*)target;
     qarr.stride[4] = (uint32_t)Z::G2;
     {
-      uint64_t pairs = 0;
-      for (const MillerTask& t : mt) pairs += t.np;
-      c->work_hint = N * pairs;
+      const MCost mc = mcost(c->curve, false);
+      double pairs = 0;
+      for (const MillerTask& t : mt)
+        for (int q = 0; q < t.np; q++) pairs += pair_fixed(t.pr[q]) ? mc.fix / mc.var : 1.0;
+      c->work_hint = (uint64_t)((double)N * pairs);
     }
-    RC(launch(c, "k_miller.rlc", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 1));
+    RC(launch(c, "k_miller.rlc", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 1,
+              (const Line<C>*)(g_line_tables ? c->line_tab.p : nullptr)));
     uint8_t* a = (uint8_t*)acc;
     RC(gt_product(c, N * ntask, (GT*)mpart, (GT*)tmp, a));
     if (ty == GS_PPE) {
@@ -1243,6 +1301,7 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
   if (const char* e = getenv("GS_COOP_FE")) c->coop_fe = atoi(e);
   if (const char* e = getenv("GS_MILLER_CH")) c->miller_ch = atoi(e);
   if (const char* e = getenv("GS_MILLER_TWIN")) c->miller_twin = atoi(e);
+  if (const char* e = getenv("GS_LINE_TABLES")) g_line_tables = atoi(e) != 0;
   if (const char* e = getenv("GS_VAR_TM")) c->var_tm = atoi(e);
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
@@ -1263,7 +1322,7 @@ void gs_ctx_destroy(gs_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& kv : c->scratch)
     if (kv.second.p) hipFree(kv.second.p);
-  for (DevBuf* b : {&c->crs_g1, &c->crs_g2, &c->tab_g1, &c->tab_g2})
+  for (DevBuf* b : {&c->crs_g1, &c->crs_g2, &c->tab_g1, &c->tab_g2, &c->line_tab})
     if (b->p) hipFree(b->p);
   for (hipStream_t st : c->side)
     if (st) hipStreamDestroy(st);

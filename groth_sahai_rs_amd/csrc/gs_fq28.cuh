@@ -218,7 +218,7 @@ template <class C> inline void fq28_check(const Fq28<C>& a, const Fq28<C>& b) {
 // register-passing wrapper: the out-of-line body takes/returns ext-vectors so that
 // operands stay in VGPRs across the call (same trick as gs_field.cuh)
 typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
-template <class C> GS_HD_NOINLINE i32x16 mul28_vec(i32x16 a, i32x16 b) {
+template <class C> GS_HD i32x16 mul28_body(i32x16 a, i32x16 b) {
   int32_t av[C::L], bv[C::L], rv[C::L];
 #pragma unroll
   for (int i = 0; i < C::L; i++) {
@@ -238,6 +238,8 @@ template <class C> GS_HD_NOINLINE i32x16 mul28_vec(i32x16 a, i32x16 b) {
   for (int i = 0; i < C::L; i++) r[i] = rv[i];
   return r;
 }
+
+template <class C> GS_HD_NOINLINE i32x16 mul28_vec(i32x16 a, i32x16 b) { return mul28_body<C>(a, b); }
 
 template <class C> GS_HD Fq28<C> mul(const Fq28<C>& a, const Fq28<C>& b) {
 #if defined(GS_FQ28_CHECK)
@@ -260,7 +262,7 @@ template <class C> GS_HD Fq28<C> mul(const Fq28<C>& a, const Fq28<C>& b) {
 }
 // squaring: its own out-of-line body on the device (L(L+1)/2 product mads against the doubled operand instead of
 // L^2, and one operand to marshal instead of two); same result and contract as mul(a, a)
-template <class C> GS_HD_NOINLINE i32x16 sqr28_vec(i32x16 a) {
+template <class C> GS_HD i32x16 sqr28_body(i32x16 a) {
   int32_t av[C::L], dv[C::L], rv[C::L];
 #pragma unroll
   for (int i = 0; i < C::L; i++) {
@@ -281,6 +283,7 @@ template <class C> GS_HD_NOINLINE i32x16 sqr28_vec(i32x16 a) {
   for (int i = 0; i < C::L; i++) r[i] = rv[i];
   return r;
 }
+template <class C> GS_HD_NOINLINE i32x16 sqr28_vec(i32x16 a) { return sqr28_body<C>(a); }
 template <class C> GS_HD Fq28<C> sqr(const Fq28<C>& a) {
 #if defined(GS_FQ28_CHECK)
   return mul(a, a);

@@ -477,16 +477,35 @@ __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, con
 // --------------------------------------------------------------------------
 // pairing side
 // --------------------------------------------------------------------------
+// Line tables of the six CRS G2 points (v0.0 v0.1 v1.0 v1.1 W2.0 W2.1), built once per CRS: one lane per point.
+template <class C> __global__ void __launch_bounds__(64, GS_WPE) k_line_tables(const uint8_t* crs_g2, Line<C>* out) {
+  int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= 6) return;
+  Aff<Fp2<C>> q;
+  aff_load<C>(q, crs_g2 + (size_t)i * AFFB(C, Fp2<C>));
+  miller_line_table<C>(out + (size_t)i * miller_line_count<C>(), q);
+}
+
+// Lanes are TASK-MAJOR: lane g works on task g / N of equation g % N, so a wave holds 64 equations of one task and its
+// lanes agree on the number of pairs and on which of them read line tables (`ltab`, pairs with Q array 2 = CRS).
 template <class C, bool TWIN>
 __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
-                                               ArrTab qarr, Fp12<C>* out, int ostride) {
+                                               ArrTab qarr, Fp12<C>* out, int ostride, const Line<C>* ltab) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
-  size_t e = g / ntask;
-  MillerTask t = tasks[g % ntask];
+  const size_t N = total / ntask;
+  const size_t ti = g / N, e = g % N;
+  const size_t go = e * ntask + ti;  // partials stay equation-major for k_final
+  MillerTask t = tasks[ti];
   Aff<Fq<C>> p0[MILLER_CH];
   Aff<Fp2<C>> qs[MILLER_CH];
   Proj2<C> ts[MILLER_CH];
+  const Line<C>* fx[MILLER_CH];
+  bool anyfx = false;  // uniform over the wave (task-major lanes)
+  for (int k = 0; k < t.np; k++) {
+    fx[k] = (ltab && t.pr[k].q_arr == 2) ? ltab + (size_t)t.pr[k].q_idx * miller_line_count<C>() : nullptr;
+    anyfx |= fx[k] != nullptr;
+  }
   if constexpr (TWIN) {
     Aff<Fq<C>> p1[MILLER_CH];
     uint8_t live[MILLER_CH];
@@ -502,9 +521,9 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, 
       }
     }
     Fp12<C> f0, f1;
-    multi_miller2(f0, f1, p0, p1, qs, t.np, ts, live);
-    out[2 * g] = f0;      // cell (0, b)
-    out[2 * g + 1] = f1;  // cell (1, b)
+    multi_miller2(f0, f1, p0, p1, qs, t.np, ts, live, anyfx ? fx : nullptr);
+    out[2 * go] = f0;      // cell (0, b)
+    out[2 * go + 1] = f1;  // cell (1, b)
   } else {
     bool live[MILLER_CH];
     for (int k = 0; k < t.np; k++) {
@@ -514,8 +533,8 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, 
       if (r.neg) p0[k].y = neg(p0[k].y);
     }
     Fp12<C> f;
-    multi_miller(f, p0, qs, t.np, ts, live);
-    out[(size_t)ostride * g] = f;  // the task's own cell (slot 0 of 2), or densely packed (batched verifier)
+    multi_miller(f, p0, qs, t.np, ts, live, anyfx ? fx : nullptr);
+    out[(size_t)ostride * go] = f;  // the task's own cell (slot 0 of 2), or densely packed (batched verifier)
   }
 }
 

@@ -90,9 +90,44 @@ template <class C> GS_HD void miller_ell(Fp12<C>& f, const Line<C>& l, const Aff
 // Multi-Miller loop over `np` pairs held in memory; pairs with an identity
 // argument are skipped (they contribute 1).  Result is NOT exponentiated.
 // `ts` is caller-provided scratch for the np running twist points.
+// Lines of a FIXED G2 argument (the CRS elements v, W2 of every GS verification) do not depend on the batch: they are
+// tabulated once per CRS in consumption order -- per loop digit the tangent line, then the chord line if the digit is
+// non-zero, then (BN) the two Frobenius chords -- and a pair whose `fixed[k]` is set reads them instead of stepping its
+// own twist point (25 of the 68 Fq multiplications of a pair-step).
+template <class C> constexpr int miller_line_count() {
+  int n = 0;
+  for (int i = C::LOOP_LEN - 2; i >= 0; i--) n += 1 + (C::LOOP[i] != 0 ? 1 : 0);
+  return n + (C::IS_BN ? 2 : 0);
+}
+template <class C> GS_HD_NOINLINE void miller_line_table(Line<C>* out, const Aff<Fp2<C>>& q) {
+  Proj2<C> t;
+  t.x = q.x;
+  t.y = q.y;
+  t.z = one_of<Fp2<C>>();
+  int n = 0;
+  for (int i = C::LOOP_LEN - 2; i >= 0; i--) {
+    miller_dbl(t, out[n++]);
+    int d = C::LOOP[i];
+    if (d != 0) {
+      Aff<Fp2<C>> qq = q;
+      if (d < 0) qq.y = neg(qq.y);
+      miller_add(t, out[n++], qq);
+    }
+  }
+  if (C::IS_BN) {
+    Aff<Fp2<C>> q1, q2;
+    q1.x = mul(conj(q.x), frob_coeff<C>(1, 2));
+    q1.y = mul(conj(q.y), frob_coeff<C>(1, 3));
+    q2.x = mul(q.x, frob_coeff<C>(2, 2));
+    q2.y = neg(mul(q.y, frob_coeff<C>(2, 3)));
+    miller_add(t, out[n++], q1);
+    miller_add(t, out[n++], q2);
+  }
+}
+
 template <class C>
 GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts,
-                                 bool* live) {
+                                 bool* live, const Line<C>* const* fixed = nullptr) {
   f12_one(f);
   bool any = false;
   for (int k = 0; k < np; k++) {
@@ -104,22 +139,33 @@ GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2
   }
   if (!any) return;
   Line<C> l;
+  int li = 0;  // position in the line tables of the fixed arguments
   for (int i = C::LOOP_LEN - 2; i >= 0; i--) {
     f12_sqr(f, f);
     for (int k = 0; k < np; k++) {
       if (!live[k]) continue;
+      if (fixed && fixed[k]) {
+        miller_ell(f, fixed[k][li], ps[k]);  // coefficients straight from the table
+        continue;
+      }
       miller_dbl(ts[k], l);
       miller_ell(f, l, ps[k]);
     }
+    li++;
     int d = C::LOOP[i];
     if (d != 0) {
       for (int k = 0; k < np; k++) {
         if (!live[k]) continue;
+        if (fixed && fixed[k]) {
+          miller_ell(f, fixed[k][li], ps[k]);
+          continue;
+        }
         Aff<Fp2<C>> q = qs[k];
         if (d < 0) q.y = neg(q.y);
         miller_add(ts[k], l, q);
         miller_ell(f, l, ps[k]);
       }
+      li++;
     }
   }
   if (C::IS_BN) {
@@ -127,6 +173,11 @@ GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2
     // pi(x', y') = (conj(x') * xi^((p-1)/3), conj(y') * xi^((p-1)/2))
     for (int k = 0; k < np; k++) {
       if (!live[k]) continue;
+      if (fixed && fixed[k]) {
+        miller_ell(f, fixed[k][li], ps[k]);
+        miller_ell(f, fixed[k][li + 1], ps[k]);
+        continue;
+      }
       Aff<Fp2<C>> q1, q2;
       q1.x = mul(conj(qs[k].x), frob_coeff<C>(1, 2));
       q1.y = mul(conj(qs[k].y), frob_coeff<C>(1, 3));
@@ -147,7 +198,8 @@ GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2
 // line of Q_k is computed once and evaluated at both: f0 *= l(P0_k), f1 *= l(P1_k).
 template <class C>
 GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0, Fp12<C>& f1, const Aff<Fq<C>>* p0, const Aff<Fq<C>>* p1,
-                                  const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts, uint8_t* live) {
+                                  const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts, uint8_t* live,
+                                  const Line<C>* const* fixed = nullptr) {
   f12_one(f0);
   f12_one(f1);
   bool any = false;
@@ -164,30 +216,49 @@ GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0, Fp12<C>& f1, const Aff<Fq<C>>* p0
   }
   if (!any) return;
   Line<C> l;
+  int li = 0;
   for (int i = C::LOOP_LEN - 2; i >= 0; i--) {
     f12_sqr(f0, f0);
     f12_sqr(f1, f1);
     for (int k = 0; k < np; k++) {
       if (!live[k]) continue;
-      miller_dbl(ts[k], l);
-      if (live[k] & 1) miller_ell(f0, l, p0[k]);
-      if (live[k] & 2) miller_ell(f1, l, p1[k]);
+      const Line<C>* lp = &l;
+      if (fixed && fixed[k])
+        lp = &fixed[k][li];
+      else
+        miller_dbl(ts[k], l);
+      if (live[k] & 1) miller_ell(f0, *lp, p0[k]);
+      if (live[k] & 2) miller_ell(f1, *lp, p1[k]);
     }
+    li++;
     int d = C::LOOP[i];
     if (d != 0) {
       for (int k = 0; k < np; k++) {
         if (!live[k]) continue;
-        Aff<Fp2<C>> q = qs[k];
-        if (d < 0) q.y = neg(q.y);
-        miller_add(ts[k], l, q);
-        if (live[k] & 1) miller_ell(f0, l, p0[k]);
-        if (live[k] & 2) miller_ell(f1, l, p1[k]);
+        const Line<C>* lp = &l;
+        if (fixed && fixed[k]) {
+          lp = &fixed[k][li];
+        } else {
+          Aff<Fp2<C>> q = qs[k];
+          if (d < 0) q.y = neg(q.y);
+          miller_add(ts[k], l, q);
+        }
+        if (live[k] & 1) miller_ell(f0, *lp, p0[k]);
+        if (live[k] & 2) miller_ell(f1, *lp, p1[k]);
       }
+      li++;
     }
   }
   if (C::IS_BN) {
     for (int k = 0; k < np; k++) {
       if (!live[k]) continue;
+      if (fixed && fixed[k]) {
+        for (int e = 0; e < 2; e++) {
+          if (live[k] & 1) miller_ell(f0, fixed[k][li + e], p0[k]);
+          if (live[k] & 2) miller_ell(f1, fixed[k][li + e], p1[k]);
+        }
+        continue;
+      }
       Aff<Fp2<C>> q1, q2;
       q1.x = mul(conj(qs[k].x), frob_coeff<C>(1, 2));
       q1.y = mul(conj(qs[k].y), frob_coeff<C>(1, 3));

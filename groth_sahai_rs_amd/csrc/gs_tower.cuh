@@ -290,7 +290,7 @@ GS_ML void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const 
 }
 // f *= l0 + (l3 + l4 v) w          -- line shape of a D-type twist (BN254)
 template <class C>
-GS_HD_NOINLINE void f12_mul_by_034(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l3, const Fp2<C>& l4) {
+GS_ML void f12_mul_by_034(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l3, const Fp2<C>& l4) {
   Fp6<C> aa, bb, s, t;
   f6_mul_fp2(aa, f.c0, l0);
   f6_mul_by_01(bb, f.c1, l3, l4);

@@ -221,3 +221,24 @@ def test_endomorphism_scalar_multiplication_random(twin, cname):
         getattr(twin, "twin_g2_smul_" + cname)(ptr(g2), ptr(c.fr(k)), ptr(out))
         want = O.g2_mul(k, P2)
         assert c.g2_dec(out) == (None if want is None else ["%x" % v for v in (want[0][0], want[0][1], want[1][0], want[1][1])]), hex(k)
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_fixed_argument_line_tables(twin, cname):
+    """Pairs whose G2 argument is tabulated (miller_line_table) give the same pairing product as stepping the twist
+    point, in the single and the twin Miller loop, for every subset of tabulated pairs."""
+    c = curve(cname)
+    ps = c.golden["pairing_sum"]
+    P = np.concatenate([c.g1(x[1]) for x in ps["x"]])
+    Q = np.concatenate([c.g2(y[1]) for y in ps["y"]])
+    n = len(ps["x"])
+    f = getattr(twin, "twin_multi_pairing_fixed_" + cname)
+    for twin_mode in (0, 1):
+        outs = []
+        for mask in (0, 1, (1 << n) - 1, 0b1010 & ((1 << n) - 1)):
+            out = np.zeros(2 * 12 * c.nq, dtype=np.uint64)
+            f(n, ptr(P), ptr(Q), mask, ptr(out), twin_mode)
+            outs.append(out)
+        assert c.f12_dec(outs[0][:12 * c.nq]) == ps["out"][3]  # cell (1, 1) of the fixture
+        for o in outs[1:]:
+            assert (o == outs[0]).all()

@@ -292,6 +292,29 @@ template <class C> struct Twin {
         multi_miller2(g, g1v, P, P, Q, nt, T, live);
         break;
       }
+      case 15:    // single Miller, nt pairs all reading line tables
+      case 16: {  // twin Miller, nt triples all reading line tables
+        constexpr int NLN = miller_line_count<C>();
+        Line<C>* tabs = new Line<C>[8 * NLN];
+        const Line<C>* fx[8];
+        for (int i = 0; i < nt; i++) {
+          miller_line_table<C>(tabs + i * NLN, Q[i]);
+          fx[i] = tabs + i * NLN;
+        }
+        Proj2<C> T[8];
+        c0 = fq28_mul_counter().load();
+        if (op == 15) {
+          bool live[8];
+          multi_miller(g, P, Q, nt, T, live, fx);
+        } else {
+          uint8_t live[8];
+          Fp12<C> g1v;
+          multi_miller2(g, g1v, P, P, Q, nt, T, live, fx);
+        }
+        long v = fq28_mul_counter().load() - c0;
+        delete[] tabs;
+        return v;
+      }
       case 11: f12_mul(g, f, f); break;
       case 12: final_exp(g, f); break;
       case 13: {  // whole 3-lane group (divide by 3 for one lane)
@@ -304,6 +327,41 @@ template <class C> struct Twin {
       default: break;
     }
     return fq28_mul_counter().load() - c0;
+  }
+  // the same with the pairs selected by `mask` reading a precomputed line table of their G2 argument
+  static void multi_pairing_fixed(int np, const uint8_t* ps, const uint8_t* qs, unsigned mask, uint8_t* o, int twin_mode) {
+    constexpr int NLN = miller_line_count<C>();
+    Aff<F1>* P = new Aff<F1>[np];
+    Aff<F2>* Q = new Aff<F2>[np];
+    Proj2<C>* T = new Proj2<C>[np];
+    Line<C>* tabs = new Line<C>[np * NLN];
+    const Line<C>** fx = new const Line<C>*[np];
+    for (int i = 0; i < np; i++) {
+      P[i] = ldg1(ps + i * 2 * NB);
+      Q[i] = ldg2(qs + i * 4 * NB);
+      fx[i] = nullptr;
+      if ((mask >> i) & 1) {
+        miller_line_table<C>(tabs + i * NLN, Q[i]);
+        fx[i] = tabs + i * NLN;
+      }
+    }
+    Fp12<C> f, f1, e;
+    if (twin_mode) {
+      uint8_t* live = new uint8_t[np];
+      multi_miller2(f, f1, P, P, Q, np, T, live, fx);
+      delete[] live;
+    } else {
+      bool* live = new bool[np];
+      multi_miller(f, P, Q, np, T, live, fx);
+      delete[] live;
+    }
+    final_exp(e, f);
+    f12_to_boundary<C>((BFq<C>*)o, e);
+    if (twin_mode) {
+      final_exp(e, f1);
+      f12_to_boundary<C>((BFq<C>*)o + 12, e);
+    }
+    delete[] P; delete[] Q; delete[] T; delete[] tabs; delete[] fx;
   }
   static void multi_pairing(int np, const uint8_t* ps, const uint8_t* qs, uint8_t* o, int do_fe) {
     Aff<F1>* P = new Aff<F1>[np];
@@ -354,6 +412,10 @@ extern "C" long twin_fq_mul_count(int reset) {
   }                                                                                                               \
   void twin_coop_##SUF(int what, const uint8_t* in, uint8_t* out) { Twin<CURVE>::coop(what, in, out); }           \
   void twin_exp_by_x_##SUF(const uint8_t* in, uint8_t* out) { Twin<CURVE>::exp_by_x(in, out); }                   \
+  void twin_multi_pairing_fixed_##SUF(int np, const uint8_t* ps, const uint8_t* qs, unsigned mask, uint8_t* o,     \
+                                      int twin_mode) {                                                           \
+    Twin<CURVE>::multi_pairing_fixed(np, ps, qs, mask, o, twin_mode);                                              \
+  }                                                                                                               \
   void twin_multi_pairing_##SUF(int np, const uint8_t* ps, const uint8_t* qs, uint8_t* o, int fe) {              \
     Twin<CURVE>::multi_pairing(np, ps, qs, o, fe);                                                                \
   }                                                                                                               \

@@ -41,6 +41,8 @@ for name in ("bls12_381", "bn254"):
 
     m = [avg(10, k, 1) for k in (1, 2, 3)]
     t = [avg(14, k, 1) for k in (1, 2, 3)]
+    mf = [avg(15, k, 1) for k in (1, 3)]
+    tf = [avg(16, k, 1) for k in (1, 3)]
     out[name] = {
         "g1_smul": avg(0, 1), "g2_smul": avg(1, 1),
         "g1_straus4_per_term": avg(2, 4) / 4, "g1_straus8_per_term": avg(2, 8) / 8,
@@ -49,6 +51,7 @@ for name in ("bls12_381", "bn254"):
         "g1_red_tail": avg(8, 2, 1), "g2_red_tail": avg(9, 2, 1),
         "miller_per_lane": m[0] - (m[2] - m[0]) / 2, "miller_per_pair": (m[2] - m[0]) / 2,
         "miller2_per_lane": t[0] - (t[2] - t[0]) / 2, "miller2_per_triple": (t[2] - t[0]) / 2,
+        "miller_per_fixed_pair": (mf[1] - mf[0]) / 2, "miller2_per_fixed_triple": (tf[1] - tf[0]) / 2,
         "f12_mul": avg(11, 1, 1), "final_exp": avg(12, 1, 1), "final_exp_coop_lane": avg(13, 1, 1) / 3,
         "mads_per_fq_mul": 2 * (14 if name == "bls12_381" else 10) ** 2,
     }
