@@ -219,6 +219,60 @@ template <class C> GS_HD Fp2<C> curve_rhs(const Fp2<C>& x) {
   return norm(add(mul(sqr(x), x), b));
 }
 
+// ---- prime-order subgroup membership of a curve point (ark-serialize's Validate::Yes) -----------------------------
+// Any correct test gives the same verdict.  BLS12-381 uses the endomorphism tests arkworks itself uses (Scott, eprint
+// 2021/1130): G1: phi'(P) = -[x^2] P with phi'(x, y) = (beta^2 x, y);  G2: psi(Q) = [x] Q -- 127- and 64-bit
+// multiplications instead of 255-bit ones.  BN254: G1 has cofactor 1 (every curve point is in the group); G2 keeps the
+// definition [r] Q = O.
+template <class F> GS_HD_NOINLINE void jac_mul_bits(Jac<F>& r, const Aff<F>& p, const uint32_t* k, int nbits) {
+  jac_set_inf(r);
+  for (int i = nbits - 1; i >= 0; i--) {
+    jac_dbl(r, r);
+    if ((k[i >> 5] >> (i & 31)) & 1) jac_madd(r, r, p);
+  }
+}
+// J == A for a Jacobian J and an affine, finite A
+template <class F> GS_HD bool jac_eq_aff(const Jac<F>& j, const Aff<F>& a) {
+  if (is_zero(j.z)) return false;
+  F z2 = sqr(j.z);
+  return eq(mul(a.x, z2), j.x) && eq(mul(a.y, mul(z2, j.z)), j.y);
+}
+template <class C> GS_HD_NOINLINE bool in_prime_subgroup(const Aff<Fq28<C>>& p) {
+  if constexpr (C::IS_BN) {
+    return true;  // cofactor 1
+  } else {
+    uint32_t x2[4];  // x^2 = lambda + 1
+    uint64_t cy = 1;
+    for (int i = 0; i < 4; i++) {
+      uint64_t t = (uint64_t)C::LAMBDA[i] + cy;
+      x2[i] = (uint32_t)t;
+      cy = t >> 32;
+    }
+    Jac<Fq28<C>> j;
+    jac_mul_bits(j, p, x2, 128);
+    Fq28<C> beta;
+    for (int i = 0; i < C::L; i++) beta.v[i] = C::BETA_28[i];
+    Aff<Fq28<C>> e = {mul(p.x, sqr(beta)), neg(p.y)};  // -phi'(P)
+    return jac_eq_aff(j, e);
+  }
+}
+template <class C> GS_HD_NOINLINE bool in_prime_subgroup(const Aff<Fp2<C>>& q) {
+  Jac<Fp2<C>> j;
+  if constexpr (C::IS_BN) {
+    uint32_t r[FrM<C>::N];
+    for (int i = 0; i < FrM<C>::N; i++) r[i] = C::R_WORDS[i];
+    jac_mul_bits(j, q, r, FrM<C>::BITS);
+    return is_zero(j.z);
+  } else {
+    uint32_t xa[2] = {C::XABS_LIMBS[0], C::XABS_LIMBS[1]};
+    jac_mul_bits(j, q, xa, 64);
+    Aff<Fp2<C>> e = q;
+    endo_apply<C>(e, 1);  // psi(Q)
+    e.y = neg(e.y);       // x < 0: psi(Q) = -[|x|] Q
+    return jac_eq_aff(j, e);
+  }
+}
+
 // Encoded sizes: compressed = NC Fq, uncompressed = 2 NC Fq
 template <class C, class F> GS_HD_NOINLINE void wire_encode_point(uint8_t* out, const Aff<F>& p, bool compressed) {
   constexpr int NC = NCoord<F>::V, B = C::N * 4;
@@ -304,16 +358,10 @@ GS_HD_NOINLINE bool wire_decode_point(Aff<F>& p, const uint8_t* in, bool compres
   }
   p.x = x;
   p.y = norm(y);
-  if (validate) {
-    Fr<C> r;
-    for (int i = 0; i < FrM<C>::N; i++) r.v[i] = C::R_WORDS[i];
-    Jac<F> J;
-    jac_smul(J, p, r);
-    if (!is_zero(J.z)) {
-      p.x = zero_of<F>();
-      p.y = zero_of<F>();
-      return false;
-    }
+  if (validate && !in_prime_subgroup<C>(p)) {
+    p.x = zero_of<F>();
+    p.y = zero_of<F>();
+    return false;
   }
   return true;
 }
