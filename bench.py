@@ -306,7 +306,7 @@ def main():
     }
     if rank == 0:
         res["roofline"] = roof
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             threads, _ = host_cores()
             sample = args.cpu_sample or max(128 * threads, 256)   # ~10-30 s of CPU work on the granted host cores
             res["cpu_baseline"] = cpu_baseline(sample, threads)
