@@ -5,7 +5,7 @@ asm block per limb count (L = 14: BLS12-381 Fq; L = 10: BN254 Fq).
 Product scanning with ONE signed 64-bit accumulator v[32:33]:
     column k:  acc += sum a_i b_(k-i)   (v_mad_i64_i32)
                acc += sum m_i p_(k-i)   (v_mad_u64_u32, i < k)
-    k <  L:    m_k = ((acc & M) * (-p^-1)) & M ; acc += m_k p_0 ; acc >>= 28
+    k <  L:    m_k = (acc * (-p^-1)) & M ; acc += m_k p_0 ; acc >>= 28
     k >= L:    r_(k-L) = acc & M ; acc >>= 28          (last: r_(L-1) = acc)
 No carry-flag instruction anywhere (they are half rate on gfx950); L*L*2 mads
 + ~5 full-rate ops per column.  Every instruction of the block is 8 bytes long and the
@@ -34,8 +34,9 @@ def gen(L):
         for i in range(max(0, k - L + 1), min(k - 1, L - 1) + 1):
             out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, R(i), P(k - i), ACC))
         if k < L:
-            out.append("v_and_b32 %s, 0xfffffff, %s" % (T, LO))
-            out.append("v_mul_lo_u32 %s, %s, %s" % (R(k), T, INV))
+            # m_k = (acc * (-p^-1)) mod 2^28: the low 28 bits of a product depend only on the operands' low 28 bits,
+            # so the accumulator's low word goes in unmasked
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R(k), LO, INV))
             out.append("v_and_b32 %s, 0xfffffff, %s" % (R(k), R(k)))
             out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, R(k), P(0), ACC))
         else:
@@ -76,8 +77,9 @@ def gen_sqr(L):
         for i in range(max(0, k - L + 1), min(k - 1, L - 1) + 1):
             out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, R(i), P(k - i), ACC))
         if k < L:
-            out.append("v_and_b32 %s, 0xfffffff, %s" % (T, LO))
-            out.append("v_mul_lo_u32 %s, %s, %s" % (R(k), T, INV))
+            # m_k = (acc * (-p^-1)) mod 2^28: the low 28 bits of a product depend only on the operands' low 28 bits,
+            # so the accumulator's low word goes in unmasked
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R(k), LO, INV))
             out.append("v_and_b32 %s, 0xfffffff, %s" % (R(k), R(k)))
             out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, R(k), P(0), ACC))
         else:
