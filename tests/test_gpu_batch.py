@@ -196,3 +196,12 @@ def test_edge_values_against_c_oracle(cname, cid, ty):
         assert int(ok[e]) == want, (ty, e, "verdict")
     assert int(ok[5]) == 1 and int(ok[2]) == 1  # untouched / randomness-free proofs of true statements still verify
     eng.close()
+
+
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])
+@pytest.mark.parametrize("ty", [0, 1, 2, 3])
+def test_small_ragged_shapes_all_types(cname, cid, ty):
+    """1 x 1, 2 x 3 and 3 x 1 equations of every type on both curves against the C oracle (the reference's own
+    statements are 2 x 1); also the smallest batches (N = 1, 3), which take the side-stream and 3-lane paths."""
+    for (m, n), N in (((1, 1), 1), ((2, 3), 3), ((3, 1), 5)):
+        _run(cid, cname, ty, N, m, n, list(range(N)))
