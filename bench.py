@@ -96,7 +96,7 @@ def alu_roofline(work, ms, curve_id, dominant):
         g = "g2" if name.endswith("g2") else "g1"
         k = name.split(".")[0]
         if k == "k_fix":
-            m = items * 32 * (255.0 / 256.0) * cnt[g + "_madd"]
+            m = items * 16 * (65535.0 / 65536.0) * cnt[g + "_madd"]  # 16-bit windows
         elif k == "k_var":
             m = lanes * cnt[g + "_smul"]
         elif k in ("k_var_multi4", "k_var_multi8"):

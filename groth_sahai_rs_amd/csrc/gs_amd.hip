@@ -47,6 +47,7 @@ struct gs_ctx {
   DevBuf crs_g2;   // 6 G2 points: v0.0 v0.1 v1.0 v1.1 W2.0 W2.1
   DevBuf tab_g1;   // 5 window tables (u0.0 u0.1 u1.0 u1.1 W1.1)
   DevBuf tab_g2;
+  DevBuf tab16_g1, tab16_g2;  // 16-bit window tables (k_build_tables16), what k_fix reads
   DevBuf line_tab;  // Miller line tables of the 6 CRS G2 points (k_line_tables)
   // scratch
   std::map<std::string, DevBuf> scratch;
@@ -227,7 +228,7 @@ template <class C> struct Sz {
                           COM1 = 2 * G1, COM2 = 2 * G2, CRS = 2 * COM1 + 2 * COM2 + G1 + G2 + GT;
 };
 
-// table ids inside tab_g1/tab_g2: 0 u0.0, 1 u0.1, 2 u1.0, 3 u1.1, 4 W.1 ; W.0 aliases u1.0
+// table ids inside tab16_g1/tab16_g2 (and the first-level tab_g1/tab_g2): 0 u0.0, 1 u0.1, 2 u1.0, 3 u1.1, 4 W.1 ; W.0 aliases u1.0
 static inline uint8_t tb_u(int k, int c) { return (uint8_t)(2 * k + c); }
 static inline uint8_t tb_w(int c) { return c ? 4 : 2; }
 
@@ -496,6 +497,11 @@ template <class C> struct Impl {
     RC(ensure(c, c->tab_g2, ne * sizeof(A2)));
     RC(launch(c, "k_build_tables.g1", k_build_tables<C, F1>, ne, 64, 5, (const uint8_t*)db1, (A1*)c->tab_g1.p));
     RC(launch(c, "k_build_tables.g2", k_build_tables<C, F2>, ne, 64, 5, (const uint8_t*)db2, (A2*)c->tab_g2.p));
+    size_t ne16 = (size_t)5 * 16 * 65536;
+    RC(ensure(c, c->tab16_g1, ne16 * sizeof(A1)));
+    RC(ensure(c, c->tab16_g2, ne16 * sizeof(A2)));
+    RC(launch(c, "k_build_tables16.g1", k_build_tables16<C, F1>, ne16, 64, 5, (const A1*)c->tab_g1.p, (A1*)c->tab16_g1.p));
+    RC(launch(c, "k_build_tables16.g2", k_build_tables16<C, F2>, ne16, 64, 5, (const A2*)c->tab_g2.p, (A2*)c->tab16_g2.p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_crs = true;
     return GS_OK;
@@ -574,7 +580,7 @@ template <class C> struct Impl {
       outs.stride[0] = (uint32_t)(m * Z::COM1);
       outs.base[1] = (uint8_t*)theta;
       outs.stride[1] = (uint32_t)(ky * Z::COM1);
-      RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs,
+      RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs,
                           ov ? c->side[1] : nullptr, c->sev[1], c->sev[2])));
     }
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
@@ -597,7 +603,7 @@ template <class C> struct Impl {
       outs.base[1] = (uint8_t*)pi;
       outs.stride[1] = (uint32_t)(kx * Z::COM2);
       if (ov) c->cur = c->side[0];  // the whole G2 side runs beside the G1 side
-      RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tab_g2.p, outs,
+      RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tab16_g2.p, outs,
                           ov ? c->side[2] : nullptr, c->sev[3], c->sev[4])));
       if (ov) {
         hipEventRecord(c->sev[5], c->side[0]);
@@ -804,7 +810,7 @@ template <class C> struct Impl {
       memset(&outs, 0, sizeof outs);
       outs.base[0] = (uint8_t*)pa;
       outs.stride[0] = (uint32_t)(vp.npa * Z::COM1);
-      RC((run_side<C, F1>(c, ".vg1", N, vp.g1, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs)));
+      RC((run_side<C, F1>(c, ".vg1", N, vp.g1, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs)));
     }
     // Miller
     const MillerTask* dmt;
@@ -953,7 +959,7 @@ template <class C> struct Impl {
       memset(&outs, 0, sizeof outs);
       outs.base[0] = (uint8_t*)s1;
       outs.stride[0] = (uint32_t)(n1 * Z::COM1);
-      RC((run_side<C, F1>(c, ".r1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs)));
+      RC((run_side<C, F1>(c, ".r1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs)));
     }
     // ---- pass 2: elements 0..n-1 = P'_j, then [PB'] , U'_k (kx), [W1'] (MSMEG2)
     int iPB = n, iU = n + (yg ? 0 : 1), iW = iU + kx, n2 = iW + (ty == GS_MSMEG2 ? 1 : 0);
@@ -1010,7 +1016,7 @@ template <class C> struct Impl {
       memset(&outs, 0, sizeof outs);
       outs.base[0] = (uint8_t*)s2;
       outs.stride[0] = (uint32_t)(n2 * Z::COM1);
-      RC((run_side<C, F1>(c, ".r2", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab_g1.p, outs)));
+      RC((run_side<C, F1>(c, ".r2", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs)));
     }
     // ---- Miller: every G2 argument once.  P arrays: 0 = S2, 1 = S1.  Q arrays: 0 ycoms, 1 B, 2 crs, 3 pi, 4 target
     std::vector<PairRef> pr;
@@ -1322,7 +1328,7 @@ void gs_ctx_destroy(gs_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& kv : c->scratch)
     if (kv.second.p) hipFree(kv.second.p);
-  for (DevBuf* b : {&c->crs_g1, &c->crs_g2, &c->tab_g1, &c->tab_g2, &c->line_tab})
+  for (DevBuf* b : {&c->crs_g1, &c->crs_g2, &c->tab_g1, &c->tab_g2, &c->tab16_g1, &c->tab16_g2, &c->line_tab})
     if (b->p) hipFree(b->p);
   for (hipStream_t st : c->side)
     if (st) hipStreamDestroy(st);
@@ -1434,10 +1440,10 @@ int gs_crs_generate_hiding(gs_ctx* c, const void* p1, const void* p2, const void
       return Impl<Bls12_381>::commit<FT<Bls12_381>>(c, n, GROUP, v, r, out, (const Aff<FT<Bls12_381>>*)c->TAB.p, TAG); \
     return Impl<Bn254>::commit<FT<Bn254>>(c, n, GROUP, v, r, out, (const Aff<FT<Bn254>>*)c->TAB.p, TAG);   \
   }
-COMMIT_DEV(gs_commit_g1_dev, Fq, true, tab_g1, ".cg1")
-COMMIT_DEV(gs_commit_g2_dev, Fp2, true, tab_g2, ".cg2")
-COMMIT_DEV(gs_commit_fr_b1_dev, Fq, false, tab_g1, ".cg1")
-COMMIT_DEV(gs_commit_fr_b2_dev, Fp2, false, tab_g2, ".cg2")
+COMMIT_DEV(gs_commit_g1_dev, Fq, true, tab16_g1, ".cg1")
+COMMIT_DEV(gs_commit_g2_dev, Fp2, true, tab16_g2, ".cg2")
+COMMIT_DEV(gs_commit_fr_b1_dev, Fq, false, tab16_g1, ".cg1")
+COMMIT_DEV(gs_commit_fr_b2_dev, Fp2, false, tab16_g2, ".cg2")
 
 #define COMMIT_HOST(NAME, DEVNAME, VSZ, KC, OSZ)                           \
   int NAME(gs_ctx* c, size_t n, const void* v, const void* r, void* out) { \

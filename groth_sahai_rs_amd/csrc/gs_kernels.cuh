@@ -153,6 +153,25 @@ __global__ void __launch_bounds__(64, GS_WPE) k_build_tables(int nb, const uint8
   tab[i] = R;
 }
 
+// Second level: 16-bit windows, tab16[(b*16 + w)*65536 + d] = d * 2^(16w) * base[b], each entry the sum of two
+// first-level entries (one mixed addition and one normalisation per lane).  1.8 GB per CRS for both groups -- a
+// fixed-base scalar then costs 16 mixed additions instead of 32.  288 GB of HBM is what makes this the right trade.
+template <class C, class F>
+__global__ void __launch_bounds__(64, GS_WPE) k_build_tables16(int nb, const Aff<F>* tab8, Aff<F>* tab16) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nb * 16 * 65536) return;
+  uint32_t d = (uint32_t)(i & 65535u);
+  int w = (int)((i >> 16) & 15), b = (int)(i >> 20);
+  Aff<F> lo = tab8[((size_t)b * 32 + 2 * w) * 256 + (d & 255u)];
+  Aff<F> hi = tab8[((size_t)b * 32 + 2 * w + 1) * 256 + (d >> 8)];
+  Jac<F> J;
+  jac_from_aff(J, lo);
+  jac_madd(J, J, hi);
+  Aff<F> R;
+  jac_to_aff(R, J);
+  tab16[i] = R;
+}
+
 // --------------------------------------------------------------------------
 // Fr preparation for prove (one lane per equation)
 // --------------------------------------------------------------------------
@@ -432,11 +451,11 @@ __global__ void __launch_bounds__(64, GS_WPE) k_fix(size_t total, int ntask, con
     int tb = term ? t.t1 : t.t0;
     if (tb == 0xFF) continue;
     Fr<C> k = pool[e * pool_n + (term ? t.s1 : t.s0)];
-    const Aff<F>* T = tab + (size_t)tb * 32 * 256;
-    for (int w = 0; w < 32; w++) {
-      uint32_t d = (k.v[w >> 2] >> ((w & 3) * 8)) & 255u;
+    const Aff<F>* T = tab + (size_t)tb * 16 * 65536;  // 16-bit windows (k_build_tables16)
+    for (int w = 0; w < 16; w++) {
+      uint32_t d = (k.v[w >> 1] >> ((w & 1) * 16)) & 65535u;
       if (d) {
-        Aff<F> q = T[w * 256 + d];
+        Aff<F> q = T[(size_t)w * 65536 + d];
         jac_madd(acc, acc, q);
       }
     }
