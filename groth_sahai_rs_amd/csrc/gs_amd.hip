@@ -45,7 +45,7 @@ struct gs_ctx {
   // CRS-derived device data
   DevBuf crs_g1;   // 6 G1 points: u0.0 u0.1 u1.0 u1.1 W1.0 W1.1
   DevBuf crs_g2;   // 6 G2 points: v0.0 v0.1 v1.0 v1.1 W2.0 W2.1
-  DevBuf tab_g1;   // 5 window tables (u0.0 u0.1 u1.0 u1.1 W1.1)
+  DevBuf tab_g1;   // first-level (8-bit) window tables of u0.0 u0.1 u1.0 u1.1 W1.1: only feed k_build_tables16
   DevBuf tab_g2;
   DevBuf tab16_g1, tab16_g2;  // 16-bit window tables (k_build_tables16), what k_fix reads
   DevBuf line_tab;  // Miller line tables of the 6 CRS G2 points (k_line_tables)
