@@ -500,8 +500,8 @@ template <class C> struct Impl {
     size_t ne16 = (size_t)5 * 16 * 65536;
     RC(ensure(c, c->tab16_g1, ne16 * sizeof(A1)));
     RC(ensure(c, c->tab16_g2, ne16 * sizeof(A2)));
-    RC(launch(c, "k_build_tables16.g1", k_build_tables16<C, F1>, ne16, 64, 5, (const A1*)c->tab_g1.p, (A1*)c->tab16_g1.p));
-    RC(launch(c, "k_build_tables16.g2", k_build_tables16<C, F2>, ne16, 64, 5, (const A2*)c->tab_g2.p, (A2*)c->tab16_g2.p));
+    RC(launch(c, "k_build_tables16.g1", k_build_tables16<C, F1>, ne16 / 16, 64, 5, (const A1*)c->tab_g1.p, (A1*)c->tab16_g1.p));
+    RC(launch(c, "k_build_tables16.g2", k_build_tables16<C, F2>, ne16 / 16, 64, 5, (const A2*)c->tab_g2.p, (A2*)c->tab16_g2.p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_crs = true;
     return GS_OK;

@@ -154,22 +154,41 @@ __global__ void __launch_bounds__(64, GS_WPE) k_build_tables(int nb, const uint8
 }
 
 // Second level: 16-bit windows, tab16[(b*16 + w)*65536 + d] = d * 2^(16w) * base[b], each entry the sum of two
-// first-level entries (one mixed addition and one normalisation per lane).  1.8 GB per CRS for both groups -- a
+// first-level entries (one mixed addition per entry, one inversion per 16 entries).  1.8 GB per CRS for both groups -- a
 // fixed-base scalar then costs 16 mixed additions instead of 32.  288 GB of HBM is what makes this the right trade.
 template <class C, class F>
 __global__ void __launch_bounds__(64, GS_WPE) k_build_tables16(int nb, const Aff<F>* tab8, Aff<F>* tab16) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)nb * 16 * 65536) return;
-  uint32_t d = (uint32_t)(i & 65535u);
-  int w = (int)((i >> 16) & 15), b = (int)(i >> 20);
-  Aff<F> lo = tab8[((size_t)b * 32 + 2 * w) * 256 + (d & 255u)];
-  Aff<F> hi = tab8[((size_t)b * 32 + 2 * w + 1) * 256 + (d >> 8)];
-  Jac<F> J;
-  jac_from_aff(J, lo);
-  jac_madd(J, J, hi);
-  Aff<F> R;
-  jac_to_aff(R, J);
-  tab16[i] = R;
+  // one lane = 16 consecutive entries (same base, window and high byte), normalised with ONE inversion
+  constexpr int G = 16;
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nb * 16 * 65536 / G) return;
+  size_t i0 = g * G;
+  uint32_t d0 = (uint32_t)(i0 & 65535u);
+  int w = (int)((i0 >> 16) & 15), b = (int)(i0 >> 20);
+  Aff<F> hi = tab8[((size_t)b * 32 + 2 * w + 1) * 256 + (d0 >> 8)];
+  Jac<F> J[G];
+  F pre[G];
+  F acc = one_of<F>();
+  for (int t = 0; t < G; t++) {
+    Aff<F> lo = tab8[((size_t)b * 32 + 2 * w) * 256 + ((d0 + t) & 255u)];
+    jac_from_aff(J[t], lo);
+    jac_madd(J[t], J[t], hi);
+    pre[t] = acc;
+    if (!is_zero_limbs(J[t].z)) acc = mul(acc, J[t].z);
+  }
+  F inv_all = inv(acc);
+  for (int t = G - 1; t >= 0; t--) {
+    Aff<F> R;
+    if (is_zero_limbs(J[t].z)) {
+      R.x = zero_of<F>();
+      R.y = zero_of<F>();
+    } else {
+      F zi = mul(inv_all, pre[t]);
+      inv_all = mul(inv_all, J[t].z);
+      jac_to_aff_zinv(R, J[t], zi);
+    }
+    tab16[i0 + t] = R;
+  }
 }
 
 // --------------------------------------------------------------------------

@@ -70,7 +70,7 @@ const char* gs_version(void);
 int gs_sizes(int curve_id, size_t out[6]);
 
 /* CRS (host pointer): uploads, derives W1 = u[1]+(O,g1), W2 = v[1]+(O,g2) and
- * builds the fixed-base window tables (16-bit windows: 1.8 GB of device memory per context, ~0.3 s) and the Miller
+ * builds the fixed-base window tables (16-bit windows: 1.8 GB of device memory per context) and the Miller
  * line tables of its G2 elements on the device. */
 int gs_set_crs(gs_ctx* ctx, const void* crs_host);
 
