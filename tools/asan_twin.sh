@@ -29,5 +29,24 @@ for cname in ("bls12_381", "bn254"):
     lm = g["left_mul"]; ks = np.concatenate([c.fr_hex(s) for s in lm["lhs"][0]])
     P2 = np.concatenate([c.g2(v[1]) for v in lm["com2"]]); out2 = np.zeros(4 * c.nq, dtype=np.uint64)
     getattr(twin, "twin_g2_msm_" + cname)(3, ptr(P2), ptr(ks), ptr(out2)); assert c.g2_dec(out2) == lm["out2"][0][1]
+    # 3-lane cooperative final exponentiation (three host threads), line tables, wire codecs
+    miller = np.zeros(12 * c.nq, dtype=np.uint64)
+    getattr(twin, "twin_multi_pairing_" + cname)(1, ptr(c.g1(pe["p"])), ptr(c.g2(pe["q"])), ptr(miller), 0)
+    out3 = np.zeros(3 * 12 * c.nq, dtype=np.uint64)
+    getattr(twin, "twin_coop_" + cname)(1, ptr(miller), ptr(out3)); assert c.f12_dec(out3[:12 * c.nq]) == pe["out"]
+    ps = g["pairing_sum"]; n = len(ps["x"])
+    P = np.concatenate([c.g1(x[1]) for x in ps["x"]]); Q = np.concatenate([c.g2(y[1]) for y in ps["y"]])
+    for tw in (0, 1):
+        o = np.zeros(2 * 12 * c.nq, dtype=np.uint64)
+        getattr(twin, "twin_multi_pairing_fixed_" + cname)(n, ptr(P), ptr(Q), (1 << n) - 1, ptr(o), tw)
+        assert c.f12_dec(o[:12 * c.nq]) == ps["out"][3]
+    for grp, pt, nb in ((1, g1, 2), (2, g2, 4)):
+        for comp in (1, 0):
+            enc = np.zeros(nb * c.nq * 8, dtype=np.uint8)
+            getattr(twin, "twin_wire_enc_" + cname)(grp, comp, ptr(pt), ptr(enc))
+            back = np.zeros(nb * c.nq, dtype=np.uint64)
+            sz = (1 if comp else 2) * (nb // 2) * c.nq * 8
+            assert getattr(twin, "twin_wire_dec_" + cname)(grp, comp, 1, ptr(enc[:sz].copy()), ptr(back)) == 1
+            assert (back == pt).all()
     print(cname, "asan/ubsan clean")
 PY
