@@ -389,10 +389,24 @@ static void build_side(SidePlan& sp, bool want_coms, int nv, int nc, bool group,
   sp.nslots = slot;
 }
 
+// the reduction launch of a side, kept back so that the caller can run the two sides' reductions side by side
+struct RedLaunch {
+  std::string name;
+  const RedTask* dred = nullptr;
+  const void* part = nullptr;
+  size_t nred = 0;
+  int nslots = 0;
+  OutTab outs;
+};
+template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLaunch& r) {
+  c->work_hint = N * (uint64_t)r.nslots;  // partial sums folded
+  return launch(c, r.name.c_str(), k_red<C, F>, N * r.nred, 64, N * r.nred, (int)r.nred, r.dred,
+                (const Jac<F>*)r.part, r.nslots, r.outs);
+}
 template <class C, class F>
 static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
                     int pool_n, const Aff<F>* tab, const OutTab& outs, hipStream_t vstream = nullptr,
-                    hipEvent_t vev0 = nullptr, hipEvent_t vev1 = nullptr) {
+                    hipEvent_t vev0 = nullptr, hipEvent_t vev1 = nullptr, RedLaunch* defer = nullptr) {
   std::string t(tag);
   const VarTask* dvar;
   const FixTask* dfix;
@@ -437,10 +451,18 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
     c->cur = base == c->stream ? nullptr : base;
     hipStreamWaitEvent(base, vev1, 0);
   }
-  c->work_hint = N * (uint64_t)sp.nslots;  // partial sums folded
-  RC(launch(c, (std::string("k_red") + tag).c_str(), k_red<C, F>, N * sp.red.size(), 64, N * sp.red.size(),
-            (int)sp.red.size(), dred, (const Jac<F>*)part, sp.nslots, outs));
-  return GS_OK;
+  RedLaunch r;
+  r.name = std::string("k_red") + tag;
+  r.dred = dred;
+  r.part = part;
+  r.nred = sp.red.size();
+  r.nslots = sp.nslots;
+  r.outs = outs;
+  if (defer) {
+    *defer = r;
+    return GS_OK;
+  }
+  return run_red<C, F>(c, N, r);
 }
 
 // ---------------------------------------------------------------------------
@@ -561,6 +583,10 @@ template <class C> struct Impl {
       hipEventRecord(c->sev[0], c->stream);
       hipStreamWaitEvent(c->side[0], c->sev[0], 0);
     }
+    // larger batches: only the two reduction kernels (one inversion chain per lane, a few hundred waves each) run
+    // side by side, after both sides' partial sums are complete
+    const bool pair_reds = !ov && c->overlap && !c->prof && c->side[0] && N * (size_t)(m + n + 4) <= 64 * c->simd_slots;
+    RedLaunch red1, red2;
     // G1 side: xcoms (m) + theta (ky).  constants A (len n) multiply S; Phi multiplies X; fixed part T.
     {
       SidePlan sp;
@@ -581,7 +607,7 @@ template <class C> struct Impl {
       outs.base[1] = (uint8_t*)theta;
       outs.stride[1] = (uint32_t)(ky * Z::COM1);
       RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs,
-                          ov ? c->side[1] : nullptr, c->sev[1], c->sev[2])));
+                          ov ? c->side[1] : nullptr, c->sev[1], c->sev[2], pair_reds ? &red1 : nullptr)));
     }
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
     {
@@ -604,12 +630,22 @@ template <class C> struct Impl {
       outs.stride[1] = (uint32_t)(kx * Z::COM2);
       if (ov) c->cur = c->side[0];  // the whole G2 side runs beside the G1 side
       RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tab16_g2.p, outs,
-                          ov ? c->side[2] : nullptr, c->sev[3], c->sev[4])));
+                          ov ? c->side[2] : nullptr, c->sev[3], c->sev[4], pair_reds ? &red2 : nullptr)));
       if (ov) {
         hipEventRecord(c->sev[5], c->side[0]);
         c->cur = nullptr;
         hipStreamWaitEvent(c->stream, c->sev[5], 0);
       }
+    }
+    if (pair_reds) {
+      hipEventRecord(c->sev[0], c->stream);  // every partial sum of both sides is enqueued before this point
+      hipStreamWaitEvent(c->side[0], c->sev[0], 0);
+      c->cur = c->side[0];
+      RC((run_red<C, F2>(c, N, red2)));
+      hipEventRecord(c->sev[5], c->side[0]);
+      c->cur = nullptr;
+      RC((run_red<C, F1>(c, N, red1)));
+      hipStreamWaitEvent(c->stream, c->sev[5], 0);
     }
     return GS_OK;
   }
