@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: Groth-Sahai proofs+verifies per second on a BLS12-381
-pairing-product-equation batch (BASELINE.json metric; configs[1] = 2^12
-independent PPEs with 4 G1 + 4 G2 variables each, one MI355X).
+pairing-product-equation batch (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N = 1)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W
+      N = 1 : the north_star target configuration, 2^16 independent PPEs (4 G1 + 4 G2 variables each) on one
+              MI355X, commit_and_prove + exact verify; the other single-GPU configurations of BASELINE.json
+              (configs[1] 2^12 PPE, configs[2] 2^16 mixed + batched verifier, configs[4] BN254 2^16) are measured
+              after it and reported under "also" on the same JSON line.
+      N > 1 : configs[3], the 2^18-equation batch sharded over the N GPUs by contiguous equation blocks
+              (2^18 / N per GPU: 2^15 at N = 8).  No data-path collective for prove / exact verify; the ranks'
+              failure counts are combined with one RCCL all-reduce INSIDE the timed step (the rank-combined verdict).
+              Launched without torchrun, this script starts its own N ranks (torch.distributed.run as a child
+              process, before anything here touches the GPU) and forwards rank 0's JSON line.
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's own launch line)
 
-One "step" = commit_and_prove + verify of every equation of the per-GPU batch
-(inputs resident in HBM).  N > 1: equations are independent, each rank owns its
-own 2^12 batch (weak scaling, no data-path collective in exact mode); ranks
-barrier, time the same K steps, rank 0 reports MAX-over-ranks time.
+One "step" = commit_and_prove + verify of every equation of the per-GPU batch (inputs resident in HBM).  Ranks
+barrier, time the same K steps, rank 0 reports MAX-over-ranks time; value = equations of all ranks / that time.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel, HIP-event timed through the library's own hook
-  cpu_baseline  oracle/gs_ref.c (CPU restatement of the reference path, NOT
-                arkworks) timed on a bounded sample on the host cores
+  roofline      dominant kernel, HIP-event timed through the library's own hook; traffic = HBM bytes per launch from
+                the committed rocprofv3 PMC passes of the same configuration (profiles/<round>/traffic_*.json)
+  cpu_baseline  oracle/gs_ref.c (CPU restatement of the reference path, NOT arkworks) timed on a bounded sample on
+                the host cores, plus the single-thread prove and verify latencies (benches/bench.rs:420-449,500-529)
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -53,8 +63,9 @@ def host_cores():
 
 
 def cpu_baseline(sample_units, threads):
-    """Time the C restatement of the reference path on `sample_units` PPE 4x4 units (all granted cores), and on two
-    units with one thread (the reference's own single-equation bench shape, BASELINE configs[0])."""
+    """Time the C restatement of the reference path on `sample_units` PPE 4x4 units (all granted cores), and one
+    equation with one thread, prove and verify SEPARATELY (the reference's own bench shape: bench_small_PPE_proof /
+    _verify, benches/bench.rs:420-449, 500-529; BASELINE configs[0])."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
         import gs_ref_py
@@ -62,7 +73,7 @@ def cpu_baseline(sample_units, threads):
         return {"value": None, "unit": "proofs+verifies/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % ex}
     t1, u1, ok1 = gs_ref_py.bench_ppe(2, 4, 4, 1)
     t, units, ok = gs_ref_py.bench_ppe(sample_units, 4, 4, threads)
-    return {
+    out = {
         "value": units / t,
         "unit": "proofs+verifies/s",
         "cores": threads,
@@ -73,6 +84,43 @@ def cpu_baseline(sample_units, threads):
         "per-op normalisation), %d threads over equations (= the CPUs granted to this process), all verified=%s, "
         "%.1f s; single thread: %.2f units/s" % (units, threads, ok and ok1, t, u1 / t1),
     }
+    try:
+        out.update(cpu_latency_split(gs_ref_py))
+    except Exception as ex:
+        out["latency_note"] = "prove/verify split unavailable: %s" % ex
+    return out
+
+
+def cpu_latency_split(ref, reps=3):
+    """Single-thread latency of ONE PPE (m = n = 4): commit_and_prove and verify timed separately on the C port, on
+    the committed golden statement shape (random scalars, generator multiples)."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gsutil import curve
+
+    c = curve("bls12_381")
+    g = c.golden["crs"]
+    crs = np.concatenate([c.com1(g["u"][0]), c.com1(g["u"][1]), c.com2(g["v"][0]), c.com2(g["v"][1]),
+                          c.g1(g["g1"]), c.g2(g["g2"]), c.f12(g["gt"])]).view(np.uint8)
+    rng = np.random.default_rng(20241220)
+    fr = lambda k: np.concatenate([c.fr(int.from_bytes(rng.bytes(40), "little") % c.r) for _ in range(k)])
+    g1m = lambda k: np.concatenate([ref.g_mul("bls12_381", 1, c.g1(g["g1"]), fr(1)) for _ in range(k)])
+    g2m = lambda k: np.concatenate([ref.g_mul("bls12_381", 2, c.g2(g["g2"]), fr(1)) for _ in range(k)])
+    m = n = 4
+    X, A, Y, B = g1m(m), g1m(n), g2m(n), g2m(m)
+    G, R, S, T = fr(m * n), fr(m * 2), fr(n * 2), fr(4)
+    tp = tv = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = ref.commit_and_prove("bls12_381", 0, m, n, X, Y, A, B, G, R, S, T, crs)
+        t1 = time.perf_counter()
+        ref.verify("bls12_381", 0, m, n, A, B, G, c.f12(g["gt"]), out["xcoms"], out["ycoms"], out["pi"], out["theta"], crs)
+        t2 = time.perf_counter()
+        tp, tv = min(tp, t1 - t0), min(tv, t2 - t1)
+    return {"prove_ms_single_thread": tp * 1e3, "verify_ms_single_thread": tv * 1e3,
+            "latency_note": "one PPE m=n=4, one thread, best of %d: commit_and_prove / verify (the verify runs on an "
+                            "unsatisfied target: same work, verdict irrelevant)" % reps}
 
 
 # measured v_mad_u64_u32 issue peak of the chip (tools/ubench.hip, profiles/r1/ubench_valu.txt: 4.34 cycles per
@@ -80,14 +128,20 @@ def cpu_baseline(sample_units, threads):
 VALU_MAD_PEAK_G = 1024 * 64 * 2.4e9 / 4.34 / 1e9
 
 
+def latest_profile(name):
+    """newest profiles/r*/<name> (committed measurement artefacts; None if absent)"""
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)),
+                  key=lambda p: int("".join(ch for ch in os.path.basename(os.path.dirname(p)) if ch.isdigit()) or 0))
+    return hits[-1] if hits else None
+
+
 def alu_roofline(work, ms, curve_id, dominant):
     """Useful Fq multiplications of one profiled step (per-kernel work items from gs_prof_get_work x the
-    per-primitive counts of profiles/r1/fq_mul_counts.json, tools/count_fq_muls.py) x 2 L^2 multiply-adds each,
+    per-primitive counts of profiles/r*/fq_mul_counts.json, tools/count_fq_muls.py) x 2 L^2 multiply-adds each,
     against the measured v_mad_u64_u32 peak: SURVEY.md 8(d)'s ALU roofline.  Kernels without an entry (scalar
     preparation, GT products, boundary conversions) count as zero, so the figure is a lower bound."""
     try:
-        cnt = json.load(open(os.path.join(ROOT, "profiles", "r1", "fq_mul_counts.json")))[
-            "bls12_381" if curve_id == 0 else "bn254"]
+        cnt = json.load(open(latest_profile("fq_mul_counts.json")))["bls12_381" if curve_id == 0 else "bn254"]
     except Exception as ex:  # the counts are a committed measurement artefact; without them report nothing
         return {"error": "fq_mul_counts.json unavailable: %s" % ex}
     muls = {}
@@ -134,13 +188,185 @@ def alu_roofline(work, ms, curve_id, dominant):
             "fq_muls_by_kernel": {k: round(v) for k, v in muls.items()}}
 
 
+def config_tag(log2n, curve, ty, mixed, mode):
+    """name of a configuration in profiles/<round>/traffic_<tag>.json and in "also" """
+    return "2p%d_%s%s%s" % (log2n, "mixed" if mixed else ["ppe", "msmeg1", "msmeg2", "quad"][ty],
+                            "_bn254" if curve == 1 else "", "_rlc" if mode == "rlc" else "")
+
+
+def pmc_traffic(tag, kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes of this configuration
+    (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction:
+    tools/pmc_pass.sh + tools/summarize_pmc.py).  None when no collection exists for the configuration."""
+    p = latest_profile("traffic_%s.json" % tag)
+    if not p:
+        return None, None
+    try:
+        tj = json.load(open(p))
+    except Exception:
+        return None, None
+    base = kernel_name.split(".")[0]
+    for k, v in tj.items():
+        if base + "<" in k and ("true" in k) == kernel_name.endswith(".twin"):
+            return v.get("hbm_bytes_per_launch_corrected"), os.path.relpath(p, ROOT)
+    return None, None
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without torchrun: start N ranks as a CHILD process (a fresh interpreter; this one has
+    not touched the GPU) and hand its output and exit code back."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+class Bench:
+    def __init__(self, args, dist, rank, world, local, dev, coll_dev):
+        self.args, self.dist, self.rank, self.world, self.local = args, dist, rank, world, local
+        self.dev, self.coll_dev = dev, coll_dev
+        self.engines = {}
+
+    def engine(self, curve):
+        import groth_sahai_rs_amd as gs
+
+        if curve not in self.engines:
+            self.engines[curve] = gs.Engine(curve, self.local)
+        return self.engines[curve]
+
+    def barrier(self):
+        import torch
+
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, log2n, curve=0, ty=0, mixed=False, mode="exact", steps=3, warmup=1, m=4, n=4, roofline=False,
+            seed_off=1):
+        """one configuration: returns the result dict (value = equations of ALL ranks per second)"""
+        import torch
+
+        from groth_sahai_rs_amd.dist import allgather_accumulators, allreduce_failures
+        from groth_sahai_rs_amd.workload import Workload
+
+        eng = self.engine(curve)
+        N = 1 << log2n
+        rank, world, dist = self.rank, self.world, self.dist
+        if mixed:  # one CRS, three sub-batches (the engine runs one type/shape per call)
+            wls = [Workload(eng, ty=0, N=N // 2, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev)]
+            for t in (1, 2):
+                wls.append(Workload(eng, ty=t, N=N // 4, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev))
+                assert (wls[-1].crs == wls[0].crs).all()
+        else:
+            wls = [Workload(eng, ty=ty, N=N, m=m, n=n, seed=20241220 + seed_off + rank, device=self.dev)]
+
+        def one_step(collective=True):
+            for w in wls:
+                w.prove()
+            if mode == "exact":
+                for w in wls:
+                    w.verify()
+                # rank-combined verdict: number of rejected proofs over all ranks (one 8-byte all-reduce over RCCL)
+                bad = sum((w.ok == 0).sum() for w in wls)
+                if collective and dist is not None:
+                    return allreduce_failures(bad, device=self.coll_dev)
+                return int(bad)
+            accs = [w.verify_rlc() for w in wls]
+            allacc = []
+            for a in accs:  # cross-GPU product of GT accumulators: all-gather (RCCL) + fixed-order local product
+                allacc += allgather_accumulators(a.to(self.coll_dev)) if collective else [a]
+            pairs = torch.cat(allacc).cpu().numpy()
+            return 0 if eng.gt_finalize(pairs) == 1 else 1
+
+        for _ in range(warmup):
+            one_step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            failures = one_step()
+            assert failures == 0, "a valid benchmark batch was rejected (%s failures)" % failures
+        eng.sync()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=self.coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+
+        # ---- correctness of what was timed: all valid proofs accepted, corrupted ones rejected
+        for w in wls:
+            w.prove()
+            bad = set(w.corrupt())
+            w.verify()
+            eng.sync()
+            ok = w.ok.cpu().numpy()
+            expect = [0 if i in bad else 1 for i in range(w.N)]
+            assert ok.tolist() == expect, "verification verdicts wrong on the benchmark batch"
+            if mode == "rlc" and bad:
+                assert eng.gt_finalize(w.verify_rlc().cpu().numpy()) == 0, "batched verifier accepted a corrupted batch"
+
+        res = {"value": N * world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+               "equations_per_gpu": N, "workload": self.describe(log2n, curve, ty, mixed, mode, m, n)}
+        if roofline and rank == 0:
+            res["roofline"] = self.roofline(eng, wls, one_step, N, curve, config_tag(log2n, curve, ty, mixed, mode))
+        for w in wls:
+            del w
+        torch.cuda.empty_cache()
+        return res
+
+    def describe(self, log2n, curve, ty, mixed, mode, m, n):
+        return "2^%d independent %s equations per GPU, m=%d n=%d, %s, commit_and_prove+verify(%s)" % (
+            log2n, "mixed 50% PPE/25% MSMEG1/25% MSMEG2" if mixed else ["PPE", "MSMEG1", "MSMEG2", "QuadEqu"][ty], m, n,
+            "BLS12-381" if curve == 0 else "BN254", mode)
+
+    def roofline(self, eng, wls, one_step, N, curve, tag):
+        """per-kernel HIP-event timing of one more step (rank 0, no collective inside the profiled step)"""
+        eng.prof_enable(True)
+        eng.prof_reset()
+        one_step(collective=False)
+        eng.sync()
+        prof = eng.prof_get()
+        work = eng.prof_get_work()
+        eng.prof_enable(False)
+        tot = sum(p[1] for p in prof) or 1.0
+        name, ms, launches = max(prof, key=lambda p: p[1])
+        avg_s = ms / max(launches, 1) / 1e3
+        bpu = sum(w.bytes_per_unit() * w.N for w in wls) / N
+        achieved = N * bpu / avg_s / 1e9
+        traffic, src = pmc_traffic(tag, name)
+        alu = alu_roofline(work, {p[0]: p[1] for p in prof}, curve, name)
+        if "fq_muls_per_step" in alu:
+            alu["fq_muls_per_unit"] = alu["fq_muls_per_step"] / N
+        return {
+            "bound": "hbm",
+            "kernel": name,
+            "achieved": achieved,
+            "peak": 8000.0,
+            "unit": "GB/s",
+            "frac": achieved / 8000.0,
+            "traffic": traffic,
+            "traffic_source": src,
+            "avg_kernel_ms": ms / max(launches, 1),
+            "bytes_per_unit": bpu,
+            "kernel_share_of_step": ms / tot,
+            "kernels_ms": {p[0]: round(p[1], 3) for p in prof},
+            "note": "integer-ALU bound path (SURVEY.md 8d): HBM fraction is ~1e-4 by construction; see alu",
+            "alu": alu,
+        }
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="0 = default for the configuration (~12 s of GPU work)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2n", type=int, default=12, help="equations per GPU (2^k); configs[1] = 12")
+    ap.add_argument("--log2n", type=int, default=0,
+                    help="equations per GPU (2^k); default 16 at one GPU, 18 - log2(gpus) otherwise (configs[3])")
     ap.add_argument("--m", type=int, default=4)
     ap.add_argument("--n", type=int, default=4)
     ap.add_argument("--curve", type=int, default=0)
@@ -149,16 +375,22 @@ def main():
                     help="verifier: exact = reference semantics (bool per equation); rlc = batched pairing-product check")
     ap.add_argument("--mixed", action="store_true", help="configs[2]: 50%% PPE, 25%% MSMEG1, 25%% MSMEG2")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the other single-GPU configurations")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU-baseline sample units (0 = auto, ~20 s)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)  # never returns
+
     import torch
-    import groth_sahai_rs_amd as gs
-    from groth_sahai_rs_amd.workload import Workload
+    import groth_sahai_rs_amd as gs  # noqa: F401
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d rank(s) were launched\n" % (args.gpus, world))
+        sys.exit(3)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -174,143 +406,67 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()  # the ranks the collective library actually sees
+        if world < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but the process group has %d rank(s)\n" % (args.gpus, world))
+            sys.exit(3)
     else:
         torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     coll_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
+
+    if not args.log2n:
+        args.log2n = 16 if world == 1 else max(18 - (world.bit_length() - 1), 10)
     N = 1 << args.log2n
+    if not args.steps:  # ~12 s of timed GPU work at the measured ~135 k units/s/GPU, at least 3 steps
+        args.steps = max(3, min(200, int(12.0 * 135e3 / N)))
 
-    eng = gs.Engine(args.curve, local)
-    if args.mixed:
-        # one CRS, three sub-batches (the engine runs one type/shape per call)
-        wls = [Workload(eng, ty=0, N=N // 2, m=args.m, n=args.n, seed=20241220 + 2 + rank, device=dev)]
-        crs = wls[0].crs
-        for ty in (1, 2):
-            wls.append(Workload(eng, ty=ty, N=N // 4, m=args.m, n=args.n, seed=20241220 + 2 + rank, device=dev))
-            assert (wls[-1].crs == crs).all()
-    else:
-        wls = [Workload(eng, ty=args.type, N=N, m=args.m, n=args.n, seed=20241220 + 1 + rank, device=dev)]
-    wl = wls[0]
-    from groth_sahai_rs_amd.dist import allgather_accumulators
+    b = Bench(args, dist, rank, world, local, dev, coll_dev)
+    main_res = b.run(args.log2n, args.curve, args.type, args.mixed, args.mode, args.steps, args.warmup, args.m, args.n,
+                     roofline=True)
 
-    def one_step(collective=True):
-        for w in wls:
-            w.prove()
-        if args.mode == "exact":
-            for w in wls:
-                w.verify()
-            return None
-        accs = [w.verify_rlc() for w in wls]
-        allacc = []
-        for a in accs:  # cross-GPU product of GT accumulators: all-gather (RCCL) + fixed-order local product
-            allacc += allgather_accumulators(a.to(coll_dev)) if collective else [a]
-        pairs = torch.cat(allacc).cpu().numpy()
-        return eng.gt_finalize(pairs)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        verdict = one_step()
-        if args.mode == "rlc":
-            assert verdict == 1, "batched verifier rejected a valid batch"
-    eng.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # ---- correctness of what was timed: all valid proofs accepted, corrupted ones rejected
-    for w in wls:
-        w.prove()
-        bad = set(w.corrupt())
-        w.verify()
-        eng.sync()
-        ok = w.ok.cpu().numpy()
-        expect = [0 if i in bad else 1 for i in range(w.N)]
-        assert ok.tolist() == expect, "verification verdicts wrong on the benchmark batch"
-        if args.mode == "rlc" and bad:
-            assert eng.gt_finalize(w.verify_rlc().cpu().numpy()) == 0, "batched verifier accepted a corrupted batch"
-
-    # ---- roofline leg: per-kernel HIP-event timing of one more step (rank 0)
-    roof = None
-    if rank == 0:
-        eng.prof_enable(True)
-        eng.prof_reset()
-        one_step(collective=False)  # rank 0 alone: no collective inside the profiled step
-        eng.sync()
-        prof = eng.prof_get()
-        eng.prof_enable(False)
-        tot = sum(p[1] for p in prof) or 1.0
-        name, ms, launches = max(prof, key=lambda p: p[1])
-        avg_s = ms / max(launches, 1) / 1e3
-        bpu = sum(w.bytes_per_unit() * w.N for w in wls) / N
-        achieved = N * bpu / avg_s / 1e9
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-            # FETCH_SIZE doubled per the gfx950 correction), valid for the default 2^12 PPE workload only
-            if args.log2n == 12 and not args.mixed and args.curve == 0 and args.type == 0 and args.mode == "exact":
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic_2p12.json")))
-                for k, v in tj.items():
-                    if name.split(".")[0] in k and ("true" in k) == name.endswith(".twin"):
-                        traffic = v["hbm_bytes_per_launch_corrected"]
-        except Exception:
-            traffic = None
-        alu = alu_roofline(eng.prof_get_work(), {p[0]: p[1] for p in prof}, args.curve, name)
-        if "fq_muls_per_step" in alu:
-            alu["fq_muls_per_unit"] = alu["fq_muls_per_step"] / N
-        roof = {
-            "bound": "hbm",
-            "kernel": name,
-            "achieved": achieved,
-            "peak": 8000.0,
-            "unit": "GB/s",
-            "frac": achieved / 8000.0,
-            "traffic": traffic,
-            "avg_kernel_ms": ms / max(launches, 1),
-            "bytes_per_unit": bpu,
-            "kernel_share_of_step": ms / tot,
-            "kernels_ms": {p[0]: round(p[1], 3) for p in prof},
-            "note": "integer-ALU bound path (SURVEY.md 8d): HBM fraction is ~1e-4 by construction; see alu",
-            "alu": alu,
-        }
-
-    total_units = N * world * args.steps
     res = {
         "metric": "GS proofs+verifies/sec (BLS12-381 PPE batch)" if args.curve == 0 and args.type == 0 else
         "GS proofs+verifies/sec (curve %d type %d)" % (args.curve, args.type),
-        "value": total_units / dt,
+        "value": main_res["value"],
         "unit": "proofs+verifies/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak",
+        # one GPU: its own batch; several: the 2^18 batch of configs[3] split over the ranks (total fixed)
+        "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "u32 limbs (381-bit Montgomery)" if args.curve == 0 else "u32 limbs (254-bit Montgomery)",
         "data": "synthetic",
-        "config": {"workload": "2^%d independent %s equations per GPU, m=%d n=%d, commit_and_prove+verify(%s)"
-                   % (args.log2n, "mixed 50%% PPE/25%% MSMEG1/25%% MSMEG2" if args.mixed else
-                      ["PPE", "MSMEG1", "MSMEG2", "QuadEqu"][args.type], args.m, args.n, args.mode),
-                   "curve": "BLS12-381" if args.curve == 0 else "BN254", "equations_per_gpu": N,
-                   "parallelism": "equation-sharded x%d" % world},
+        "config": {"workload": main_res["workload"], "curve": "BLS12-381" if args.curve == 0 else "BN254",
+                   "equations_per_gpu": N, "total_equations": N * world,
+                   "parallelism": "equation-sharded x%d%s" % (world, ", failure counts all-reduced (RCCL) every step"
+                                                              if world > 1 and args.mode == "exact" else "")},
     }
     if rank == 0:
-        res["roofline"] = roof
+        res["roofline"] = main_res.get("roofline")
+        default_cfg = args.curve == 0 and args.type == 0 and not args.mixed and args.mode == "exact"
+        if world == 1 and not args.no_also and default_cfg:
+            also = {}
+            for tag, kw, st in (("2p12_ppe", dict(log2n=12), 10), ("2p16_mixed", dict(log2n=16, mixed=True), 3),
+                                ("2p16_mixed_rlc", dict(log2n=16, mixed=True, mode="rlc"), 3),
+                                ("2p16_ppe_bn254", dict(log2n=16, curve=1), 3)):
+                if kw.get("log2n") == args.log2n and len(kw) == 1:
+                    continue
+                r = b.run(steps=st, warmup=1, roofline=True, seed_off=3, **kw)
+                rf = r.get("roofline") or {}
+                also[tag] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": st, "workload": r["workload"],
+                             "dominant_kernel": rf.get("kernel"), "alu_frac": (rf.get("alu") or {}).get("frac"),
+                             "kernels_ms": rf.get("kernels_ms")}
+            res["also"] = also
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             threads, _ = host_cores()
             sample = args.cpu_sample or max(128 * threads, 256)   # ~10-30 s of CPU work on the granted host cores
             res["cpu_baseline"] = cpu_baseline(sample, threads)
         print(json.dumps(res))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

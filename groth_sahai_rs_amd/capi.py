@@ -13,13 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/gs_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "gs_ctx_create", "gs_ctx_destroy", "gs_set_stream", "gs_sync", "gs_last_error", "gs_version", "gs_sizes",
+    "gs_ctx_create", "gs_ctx_destroy", "gs_set_stream", "gs_set_option", "gs_sync", "gs_last_error", "gs_version", "gs_sizes",
     "gs_set_crs", "gs_crs_generate", "gs_crs_generate_hiding",
     "gs_commit_g1_dev", "gs_commit_g2_dev", "gs_commit_fr_b1_dev", "gs_commit_fr_b2_dev",
     "gs_commit_g1", "gs_commit_g2", "gs_commit_fr_b1", "gs_commit_fr_b2",
     "gs_prove_batch_dev", "gs_prove_batch", "gs_verify_batch_dev", "gs_verify_batch",
     "gs_verify_batch_rlc_dev", "gs_verify_batch_rlc", "gs_gt_finalize",
-    "gs_mat_left_mul_com1", "gs_mat_left_mul_com2", "gs_pairing_sum",
+    "gs_mat_left_mul_com1", "gs_mat_left_mul_com2", "gs_pairing_sum", "gs_fr_matmul",
     "gs_g1_mul_batch", "gs_g2_mul_batch", "gs_g1_mul_batch_dev", "gs_g2_mul_batch_dev",
     "gs_multi_pairing_batch", "gs_multi_pairing_batch_dev", "gs_gt_pow_batch_dev",
     "gs_wire_sizes", "gs_wire_encode_g1", "gs_wire_encode_g2", "gs_wire_decode_g1", "gs_wire_decode_g2",
@@ -78,6 +78,24 @@ def _p(a):
     return ctypes.c_void_p(a.data_ptr())
 
 
+def _nbytes(a):
+    if isinstance(a, np.ndarray):
+        return a.nbytes
+    return a.numel() * a.element_size()  # torch tensor
+
+
+def _need(code_name, arrays):
+    """Every (name, array, bytes) must hold exactly that many bytes: the C ABI takes bare pointers, so a short proof
+    (lengths come from the wire) would otherwise be read past its end.  The reference panics at this point
+    (pairing_sum / left_mul asserts, data_structures.rs:495,705): GS_ERR_SHAPE."""
+    for name, a, want in arrays:
+        if a is None:
+            continue
+        got = _nbytes(a)
+        if got != want:
+            raise GsError(1, "%s: %s holds %d bytes, the shape needs %d" % (code_name, name, got, want))
+
+
 class Engine:
     """One gs_ctx: one GPU, one stream, one CRS."""
 
@@ -115,6 +133,11 @@ class Engine:
     def sync(self):
         self._chk(self.lib.gs_sync(self.ctx))
 
+    def set_option(self, key, value):
+        """Planner override (include/gs_amd.h, gs_set_option): miller_twin, miller_ch, var_tm, coop_fe, line_tables,
+        overlap.  Results never change, only which kernel shapes run."""
+        self._chk(self.lib.gs_set_option(self.ctx, key.encode(), int(value)))
+
     def set_crs(self, crs):
         crs = np.ascontiguousarray(crs).view(np.uint8).reshape(-1)
         assert crs.size == self.CRS, (crs.size, self.CRS)
@@ -127,7 +150,8 @@ class Engine:
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         out = self._out(self.CRS)
         fn = self.lib.gs_crs_generate_hiding if hiding else self.lib.gs_crs_generate
-        self._chk(fn(self.ctx, _p(u8(p1)), _p(u8(p2)), _p(u8(scalars)), _p(out)))
+        p1, p2, scalars = u8(p1), u8(p2), u8(scalars)  # named: the buffers must outlive the call
+        self._chk(fn(self.ctx, _p(p1), _p(p2), _p(scalars), _p(out)))
         return out
 
     # -- shapes ---------------------------------------------------------------
@@ -136,6 +160,27 @@ class Engine:
         return dict(xg=xg, yg=yg, kx=2 if xg else 1, ky=2 if yg else 1, sx=self.G1 if xg else self.FR,
                     sy=self.G2 if yg else self.FR,
                     st={GS_PPE: self.GT, GS_MSMEG1: self.G1, GS_MSMEG2: self.G2, GS_QUAD: self.FR}[ty])
+
+    def _check_prove(self, fn, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, xcoms=None, ycoms=None, pi=None, theta=None):
+        if not (0 <= ty <= 3) or m < 1 or n < 1:
+            raise GsError(1, "%s: bad equation type or empty variable list" % fn)
+        sh = self.shape(ty)
+        kx, ky, sx, sy = sh["kx"], sh["ky"], sh["sx"], sh["sy"]
+        _need(fn, [("X", X, N * m * sx), ("Y", Y, N * n * sy), ("A", A, N * n * sx), ("B", B, N * m * sy),
+                   ("Gamma", Gamma, N * m * n * self.FR), ("R", R, N * m * kx * self.FR),
+                   ("S", S, N * n * ky * self.FR), ("T", T, N * ky * kx * self.FR),
+                   ("xcoms", xcoms, N * m * self.COM1), ("ycoms", ycoms, N * n * self.COM2),
+                   ("pi", pi, N * kx * self.COM2), ("theta", theta, N * ky * self.COM1)])
+
+    def _check_verify(self, fn, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta):
+        if not (0 <= ty <= 3) or m < 1 or n < 1:
+            raise GsError(1, "%s: bad equation type or empty variable list" % fn)
+        sh = self.shape(ty)
+        kx, ky, sx, sy, st = sh["kx"], sh["ky"], sh["sx"], sh["sy"], sh["st"]
+        _need(fn, [("A", A, N * n * sx), ("B", B, N * m * sy), ("Gamma", Gamma, N * m * n * self.FR),
+                   ("target", target, N * st), ("xcoms", xcoms, N * m * self.COM1),
+                   ("ycoms", ycoms, N * n * self.COM2), ("pi", pi, N * kx * self.COM2),
+                   ("theta", theta, N * ky * self.COM1)])
 
     # -- host entry points (numpy uint8/uint64 arrays) --------------------------
     def _out(self, nbytes):
@@ -156,6 +201,8 @@ class Engine:
     def prove_batch(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, want_coms=True):
         sh = self.shape(ty)
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        X, Y, A, B, Gamma, R, S, T = map(u8, (X, Y, A, B, Gamma, R, S, T))
+        self._check_prove("gs_prove_batch", ty, N, m, n, X, Y, A, B, Gamma, R, S, T)
         xc = self._out(N * m * self.COM1) if want_coms else None
         yc = self._out(N * n * self.COM2) if want_coms else None
         pi = self._out(N * sh["kx"] * self.COM2)
@@ -168,6 +215,8 @@ class Engine:
     def verify_batch(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta):
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         ok = np.zeros(N, dtype=np.uint8)
+        A, B, Gamma, target, xcoms, ycoms, pi, theta = map(u8, (A, B, Gamma, target, xcoms, ycoms, pi, theta))
+        self._check_verify("gs_verify_batch", ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta)
         self._chk(self.lib.gs_verify_batch(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(A)), _p(u8(B)),
                                            _p(u8(Gamma)), _p(u8(target)), _p(u8(xcoms)), _p(u8(ycoms)), _p(u8(pi)),
                                            _p(u8(theta)), _p(ok)))
@@ -177,7 +226,9 @@ class Engine:
         """Batched verifier (host buffers).  rho: uint64[N*4].  Returns (ok_all, acc_pair_bytes)."""
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         rho = np.ascontiguousarray(rho, dtype=np.uint64).reshape(-1)
-        assert rho.size == 4 * N
+        A, B, Gamma, target, xcoms, ycoms, pi, theta = map(u8, (A, B, Gamma, target, xcoms, ycoms, pi, theta))
+        self._check_verify("gs_verify_batch_rlc", ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta)
+        _need("gs_verify_batch_rlc", [("rho", rho, 32 * N)])
         acc = self._out(2 * self.GT)
         ok = np.zeros(1, dtype=np.uint8)
         self._chk(self.lib.gs_verify_batch_rlc(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(A)), _p(u8(B)),
@@ -198,13 +249,29 @@ class Engine:
         osz = self.COM1 if group == 1 else self.COM2
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         out = self._out(rows * osz)
-        self._chk(fn(self.ctx, rows, k, _p(u8(lhs)), _p(u8(col)), _p(out)))
+        lhs, col = u8(lhs), u8(col)
+        _need("gs_mat_left_mul", [("lhs", lhs, rows * k * self.FR), ("col", col, k * osz)])
+        self._chk(fn(self.ctx, rows, k, _p(lhs), _p(col), _p(out)))
         return out.reshape(rows, osz)
+
+    def fr_matmul(self, lhs, rhs):
+        """Matrix<Fr> product (lists of rows of 4 x u64 Montgomery scalars) on the prover's preparation kernels."""
+        rows, inner, cols = len(lhs), len(lhs[0]), len(rhs[0])
+        assert len(rhs) == inner and all(len(r) == inner for r in lhs) and all(len(r) == cols for r in rhs)
+        u8 = lambda mat: np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.uint64).reshape(-1) for r in mat
+                                                        for v in r])).view(np.uint8).reshape(-1)
+        out = self._out(rows * cols * self.FR)
+        a, b = u8(lhs), u8(rhs)  # named: the buffers must outlive the call
+        self._chk(self.lib.gs_fr_matmul(self.ctx, rows, inner, cols, _p(a), _p(b), _p(out)))
+        o = out.view(np.uint64).reshape(rows, cols, self.FR // 8)
+        return [[o[i, j].copy() for j in range(cols)] for i in range(rows)]
 
     def pairing_sum(self, k, x, y):
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         out = self._out(4 * self.GT)
-        self._chk(self.lib.gs_pairing_sum(self.ctx, k, _p(u8(x)), _p(u8(y)), _p(out)))
+        x, y = u8(x), u8(y)
+        _need("gs_pairing_sum", [("x", x, k * self.COM1), ("y", y, k * self.COM2)])
+        self._chk(self.lib.gs_pairing_sum(self.ctx, k, _p(x), _p(y), _p(out)))
         return out.reshape(4, self.GT)
 
     def g_mul_batch(self, group, points, scalars, broadcast=False):
@@ -214,26 +281,35 @@ class Engine:
         k = u8(scalars)
         n = k.size // self.FR
         out = self._out(n * gsz)
-        self._chk(fn(self.ctx, ctypes.c_size_t(n), _p(u8(points)), 1 if broadcast else 0, _p(k), _p(out)))
+        points = u8(points)
+        _need("gs_g_mul_batch", [("points", points, (1 if broadcast else n) * gsz)])
+        self._chk(fn(self.ctx, ctypes.c_size_t(n), _p(points), 1 if broadcast else 0, _p(k), _p(out)))
         return out.reshape(n, gsz)
 
     def multi_pairing_batch(self, n, k, P, Q):
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         out = self._out(n * self.GT)
-        self._chk(self.lib.gs_multi_pairing_batch(self.ctx, ctypes.c_size_t(n), k, _p(u8(P)), _p(u8(Q)), _p(out)))
+        P, Q = u8(P), u8(Q)
+        _need("gs_multi_pairing_batch", [("P", P, n * k * self.G1), ("Q", Q, n * k * self.G2)])
+        self._chk(self.lib.gs_multi_pairing_batch(self.ctx, ctypes.c_size_t(n), k, _p(P), _p(Q), _p(out)))
         return out.reshape(n, self.GT)
 
     # -- device entry points (torch CUDA uint8 tensors; asynchronous) --------------
     def prove_batch_dev(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, xcoms, ycoms, pi, theta):
+        self._check_prove("gs_prove_batch_dev", ty, N, m, n, X, Y, A, B, Gamma, R, S, T, xcoms, ycoms, pi, theta)
         self._chk(self.lib.gs_prove_batch_dev(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(X), _p(Y), _p(A), _p(B),
                                               _p(Gamma), _p(R), _p(S), _p(T), _p(xcoms), _p(ycoms), _p(pi),
                                               _p(theta)))
 
     def verify_batch_dev(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, ok):
+        self._check_verify("gs_verify_batch_dev", ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta)
+        _need("gs_verify_batch_dev", [("ok", ok, N)])
         self._chk(self.lib.gs_verify_batch_dev(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(A), _p(B), _p(Gamma),
                                                _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(ok)))
 
     def verify_batch_rlc_dev(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, rho, acc):
+        self._check_verify("gs_verify_batch_rlc_dev", ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta)
+        _need("gs_verify_batch_rlc_dev", [("rho", rho, 32 * N), ("acc", acc, 2 * self.GT)])
         self._chk(self.lib.gs_verify_batch_rlc_dev(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(A), _p(B), _p(Gamma),
                                                    _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(rho),
                                                    _p(acc)))

@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -36,21 +38,42 @@ struct ProfEntry {
   uint64_t work = 0;   // kernel-specific work items (scalars, slots, pairs ...; = lanes when no hint was given)
 };
 
+// Everything derived from one CRS on one device: immutable once built, shared (reference-counted) by every context of
+// this process that installs the same CRS bytes on the same device -- Rayon-style callers keep one context per worker
+// and would otherwise hold 1.8 GB of identical 16-bit window tables each.
+struct CrsTables {
+  int device = 0, curve = 0;
+  std::vector<uint8_t> crs_bytes;
+  DevBuf crs_g1;   // 6 G1 points: u0.0 u0.1 u1.0 u1.1 W1.0 W1.1
+  DevBuf crs_g2;   // 6 G2 points: v0.0 v0.1 v1.0 v1.1 W2.0 W2.1
+  DevBuf tab16_g1, tab16_g2;  // 16-bit window tables (k_build_tables16), what k_fix reads
+  DevBuf line_tab;  // Miller line tables of the 6 CRS G2 points (k_line_tables)
+  ~CrsTables() {
+    hipSetDevice(device);
+    for (DevBuf* b : {&crs_g1, &crs_g2, &tab16_g1, &tab16_g2, &line_tab})
+      if (b->p) hipFree(b->p);
+  }
+};
+static std::mutex g_tables_mu;
+static std::vector<std::weak_ptr<CrsTables>> g_tables;
+
+struct PlanEntry {  // an uploaded task table: device copy + the host bytes it was made from
+  DevBuf dev;
+  std::vector<uint8_t> host;
+  uint64_t last_use = 0;
+};
+
 struct gs_ctx {
   int curve = 0;
   int device = 0;
   hipStream_t stream = nullptr;
   bool have_crs = false;
   std::string err;
-  // CRS-derived device data
-  DevBuf crs_g1;   // 6 G1 points: u0.0 u0.1 u1.0 u1.1 W1.0 W1.1
-  DevBuf crs_g2;   // 6 G2 points: v0.0 v0.1 v1.0 v1.1 W2.0 W2.1
-  DevBuf tab_g1;   // first-level (8-bit) window tables of u0.0 u0.1 u1.0 u1.1 W1.1: only feed k_build_tables16
-  DevBuf tab_g2;
-  DevBuf tab16_g1, tab16_g2;  // 16-bit window tables (k_build_tables16), what k_fix reads
-  DevBuf line_tab;  // Miller line tables of the 6 CRS G2 points (k_line_tables)
+  std::shared_ptr<CrsTables> tabs;  // CRS-derived device data (shared between contexts, see CrsTables)
   // scratch
   std::map<std::string, DevBuf> scratch;
+  std::map<std::string, PlanEntry> plans;  // task tables by (name, size, content hash); content compared on a hit
+  uint64_t plan_clock = 0;
   // profiling
   bool prof = false;
   std::map<std::string, ProfEntry> prof_map;
@@ -65,9 +88,11 @@ struct gs_ctx {
   bool overlap = true;
   // SIMD slots of the device (CUs x 4); every heavy kernel runs one 512-VGPR wave per SIMD
   size_t simd_slots = 1024;
-  int var_tm = 0;  // 0 = planned (pick_tm); GS_VAR_TM overrides
-  int miller_ch = 0, miller_twin = -1;  // 0 / -1 = planned per batch (miller_cost); GS_MILLER_CH / GS_MILLER_TWIN override
+  // planner overrides (gs_set_option; 0 / -1 = planned per batch)
+  int var_tm = 0;
+  int miller_ch = 0, miller_twin = -1;
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
+  bool line_tables = true;  // pairs whose G2 argument is a CRS element read precomputed Miller lines
 };
 
 static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -88,7 +113,14 @@ static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess
 
 static int ensure(gs_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return GS_OK;
-  if (b.p) hipFree(b.p);
+  if (b.p) {  // growing: kernels already enqueued may still read the old buffer
+    if (c) {
+      hipStreamSynchronize(c->stream);
+      for (hipStream_t st : c->side)
+        if (st) hipStreamSynchronize(st);
+    }
+    hipFree(b.p);
+  }
   b.p = nullptr;
   b.cap = 0;
   size_t want = bytes < 256 ? 256 : bytes;
@@ -118,19 +150,18 @@ static inline MCost mcost(int curve, bool twin) {
   if (curve == 0) return twin ? MCost{4536.0, 7545.0, 5848.0} : MCost{2268.0, 4621.0, 2924.0};
   return twin ? MCost{4680.0, 9991.0, 7568.0} : MCost{2340.0, 6207.0, 3784.0};
 }
-static bool g_line_tables = true;  // GS_LINE_TABLES=0 disables the table-reading pairs (experiments)
-static inline bool pair_fixed(const PairRef& r) { return g_line_tables && r.q_arr == 2; }  // Q array 2 = CRS (v, W2)
+static inline bool pair_fixed(bool lt, const PairRef& r) { return lt && r.q_arr == 2; }  // Q array 2 = CRS (v, W2)
 // Split one cell's pairs into the fewest tasks whose lane cost stays within `budget`: costly pairs first, each to the
 // lightest task that still has room (LPT).
 static void chunk_tasks(std::vector<MillerTask>& mt, const std::vector<PairRef>& pr, double budget, int b, bool single,
-                        const MCost& mc) {
+                        const MCost& mc, bool lt) {
   size_t P = pr.size();
   if (P == 0) return;
   std::vector<size_t> order;
   for (size_t i = 0; i < P; i++)
-    if (!pair_fixed(pr[i])) order.push_back(i);
+    if (!pair_fixed(lt, pr[i])) order.push_back(i);
   for (size_t i = 0; i < P; i++)
-    if (pair_fixed(pr[i])) order.push_back(i);
+    if (pair_fixed(lt, pr[i])) order.push_back(i);
   for (size_t nt = (P + MILLER_CH - 1) / MILLER_CH; nt <= P; nt++) {
     std::vector<double> load(nt, 0.0);
     std::vector<std::vector<size_t>> members(nt);
@@ -139,7 +170,7 @@ static void chunk_tasks(std::vector<MillerTask>& mt, const std::vector<PairRef>&
       for (size_t t = 0; t < nt; t++)
         if (members[t].size() < (size_t)MILLER_CH && (best == nt || load[t] < load[best])) best = t;
       members[best].push_back(idx);
-      load[best] += pair_fixed(pr[idx]) ? mc.fix : mc.var;
+      load[best] += pair_fixed(lt, pr[idx]) ? mc.fix : mc.var;
     }
     double mx = 0;
     for (double l : load) mx = l > mx ? l : mx;
@@ -161,7 +192,7 @@ static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTas
   double lane = 0;
   for (const MillerTask& t : mt) {
     double l = mc.base;
-    for (int q = 0; q < t.np; q++) l += pair_fixed(t.pr[q]) ? mc.fix : mc.var;
+    for (int q = 0; q < t.np; q++) l += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix : mc.var;
     lane = l > lane ? l : lane;
   }
   double waves = (double)mt.size() * (double)((N + 63) / 64);
@@ -232,20 +263,50 @@ template <class C> struct Sz {
 static inline uint8_t tb_u(int k, int c) { return (uint8_t)(2 * k + c); }
 static inline uint8_t tb_w(int c) { return c ? 4 : 2; }
 
-// Task tables are immutable once uploaded: they are cached per (name, content
-// hash) so that a later batch never overwrites a table an in-flight kernel reads.
+// Task tables are immutable once uploaded: they are cached per (name, size, content hash) so that a later batch never
+// overwrites a table an in-flight kernel reads.  The host bytes are kept and compared on a hit (a hash collision gets
+// its own entry instead of silently reusing the wrong plan); the cache is capped: past GS_PLAN_CAP entries the least
+// recently used ones are freed after a stream sync (shapes seen long ago by a long-lived context).
+constexpr size_t GS_PLAN_CAP = 256;
+static int plan_evict(gs_ctx* c) {
+  if (c->plans.size() <= GS_PLAN_CAP) return GS_OK;
+  hipStreamSynchronize(c->stream);
+  for (hipStream_t st : c->side)
+    if (st) hipStreamSynchronize(st);
+  while (c->plans.size() > GS_PLAN_CAP / 2) {
+    auto victim = c->plans.begin();
+    for (auto it = c->plans.begin(); it != c->plans.end(); ++it)
+      if (it->second.last_use < victim->second.last_use) victim = it;
+    if (victim->second.dev.p) hipFree(victim->second.dev.p);
+    c->plans.erase(victim);
+  }
+  return GS_OK;
+}
 template <class T> static int upload(gs_ctx* c, const char* name, const std::vector<T>& v, const T** out) {
   uint64_t h = 1469598103934665603ull;
   const uint8_t* b = (const uint8_t*)v.data();
-  for (size_t i = 0; i < v.size() * sizeof(T); i++) h = (h ^ b[i]) * 1099511628211ull;
-  char key[160];
-  snprintf(key, sizeof key, "plan%s.%zu.%016llx", name, v.size(), (unsigned long long)h);
-  bool fresh = !c->scratch.count(key);
-  void* p;
-  RC(scratch(c, key, v.size() * sizeof(T) + 16, &p));
-  if (fresh && !v.empty()) HIPCHK(c, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  *out = (const T*)p;
-  return GS_OK;
+  const size_t nb = v.size() * sizeof(T);
+  for (size_t i = 0; i < nb; i++) h = (h ^ b[i]) * 1099511628211ull;
+  for (int salt = 0;; salt++) {
+    char key[176];
+    snprintf(key, sizeof key, "plan%s.%zu.%016llx.%d", name, v.size(), (unsigned long long)h, salt);
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) {
+      PlanEntry& e = it->second;
+      if (e.host.size() != nb || (nb && memcmp(e.host.data(), b, nb) != 0)) continue;  // collision: next salt
+      e.last_use = ++c->plan_clock;
+      *out = (const T*)e.dev.p;
+      return GS_OK;
+    }
+    RC(plan_evict(c));
+    PlanEntry& e = c->plans[key];
+    e.host.assign(b, b + nb);
+    e.last_use = ++c->plan_clock;
+    RC(ensure(c, e.dev, nb + 16));
+    if (nb) HIPCHK(c, hipMemcpy(e.dev.p, b, nb, hipMemcpyHostToDevice));
+    *out = (const T*)e.dev.p;
+    return GS_OK;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -479,6 +540,30 @@ template <class C> struct Impl {
 
   static int set_crs(gs_ctx* c, const void* crs_host) {
     const uint8_t* h = (const uint8_t*)crs_host;
+    // an identical CRS already installed on this device (by any context of the process)?  share its tables
+    {
+      std::lock_guard<std::mutex> lk(g_tables_mu);
+      for (auto it = g_tables.begin(); it != g_tables.end();) {
+        std::shared_ptr<CrsTables> t = it->lock();
+        if (!t) {
+          it = g_tables.erase(it);
+          continue;
+        }
+        if (t->device == c->device && t->curve == c->curve && t->crs_bytes.size() == Z::CRS &&
+            memcmp(t->crs_bytes.data(), h, Z::CRS) == 0) {
+          c->tabs = t;
+          c->have_crs = true;
+          return GS_OK;
+        }
+        ++it;
+      }
+    }
+    std::shared_ptr<CrsTables> tb = std::make_shared<CrsTables>();
+    tb->device = c->device;
+    tb->curve = c->curve;
+    tb->crs_bytes.assign(h, h + Z::CRS);
+    c->have_crs = false;
+    c->tabs = tb;  // (a failed build leaves have_crs false; the tables die with the last reference)
     // device copies (boundary form): 6 G1 points u0.0 u0.1 u1.0 u1.1 W1.0 W1.1, same for G2
     std::vector<uint8_t> g1pts(6 * Z::G1), g2pts(6 * Z::G2);
     memcpy(&g1pts[0], h, 4 * Z::G1);
@@ -491,18 +576,18 @@ template <class C> struct Impl {
     memcpy(&g2pts[4 * Z::G2], &g2pts[2 * Z::G2], Z::G2);
     memcpy(&g1pts[5 * Z::G1], g1, Z::G1);
     memcpy(&g2pts[5 * Z::G2], g2, Z::G2);
-    RC(ensure(c, c->crs_g1, g1pts.size()));
-    RC(ensure(c, c->crs_g2, g2pts.size()));
-    HIPCHK(c, hipMemcpy(c->crs_g1.p, g1pts.data(), g1pts.size(), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->crs_g2.p, g2pts.data(), g2pts.size(), hipMemcpyHostToDevice));
-    RC(launch(c, "k_crs_derive.g1", k_crs_derive<C, F1>, 1, 64, (uint8_t*)c->crs_g1.p));
-    RC(launch(c, "k_crs_derive.g2", k_crs_derive<C, F2>, 1, 64, (uint8_t*)c->crs_g2.p));
+    RC(ensure(c, tb->crs_g1, g1pts.size()));
+    RC(ensure(c, tb->crs_g2, g2pts.size()));
+    HIPCHK(c, hipMemcpy(tb->crs_g1.p, g1pts.data(), g1pts.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(tb->crs_g2.p, g2pts.data(), g2pts.size(), hipMemcpyHostToDevice));
+    RC(launch(c, "k_crs_derive.g1", k_crs_derive<C, F1>, 1, 64, (uint8_t*)tb->crs_g1.p));
+    RC(launch(c, "k_crs_derive.g2", k_crs_derive<C, F2>, 1, 64, (uint8_t*)tb->crs_g2.p));
     // Miller line tables of the six G2 points (v0, v1, W2): the verifier pairs theta / PB against them
-    RC(ensure(c, c->line_tab, 6 * (size_t)miller_line_count<C>() * sizeof(Line<C>)));
-    RC(launch(c, "k_line_tables", k_line_tables<C>, 6, 64, (const uint8_t*)c->crs_g2.p, (Line<C>*)c->line_tab.p));
+    RC(ensure(c, tb->line_tab, 6 * (size_t)miller_line_count<C>() * sizeof(Line<C>)));
+    RC(launch(c, "k_line_tables", k_line_tables<C>, 6, 64, (const uint8_t*)tb->crs_g2.p, (Line<C>*)tb->line_tab.p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(g1pts.data(), c->crs_g1.p, g1pts.size(), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g2pts.data(), c->crs_g2.p, g2pts.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g1pts.data(), tb->crs_g1.p, g1pts.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g2pts.data(), tb->crs_g2.p, g2pts.size(), hipMemcpyDeviceToHost));
     // window tables (internal form) for bases {u0.0,u0.1,u1.0,u1.1,W.1}
     std::vector<uint8_t> b1(5 * Z::G1), b2(5 * Z::G2);
     memcpy(&b1[0], &g1pts[0], 4 * Z::G1);
@@ -514,17 +599,23 @@ template <class C> struct Impl {
     RC(scratch(c, "crs.b2", b2.size(), &db2));
     HIPCHK(c, hipMemcpy(db1, b1.data(), b1.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(db2, b2.data(), b2.size(), hipMemcpyHostToDevice));
+    // first-level (8-bit) window tables only feed k_build_tables16: context scratch, reused by the next CRS
     size_t ne = (size_t)5 * 32 * 256;
-    RC(ensure(c, c->tab_g1, ne * sizeof(A1)));
-    RC(ensure(c, c->tab_g2, ne * sizeof(A2)));
-    RC(launch(c, "k_build_tables.g1", k_build_tables<C, F1>, ne, 64, 5, (const uint8_t*)db1, (A1*)c->tab_g1.p));
-    RC(launch(c, "k_build_tables.g2", k_build_tables<C, F2>, ne, 64, 5, (const uint8_t*)db2, (A2*)c->tab_g2.p));
+    void *t8g1, *t8g2;
+    RC(scratch(c, "crs.tab8.g1", ne * sizeof(A1), &t8g1));
+    RC(scratch(c, "crs.tab8.g2", ne * sizeof(A2), &t8g2));
+    RC(launch(c, "k_build_tables.g1", k_build_tables<C, F1>, ne, 64, 5, (const uint8_t*)db1, (A1*)t8g1));
+    RC(launch(c, "k_build_tables.g2", k_build_tables<C, F2>, ne, 64, 5, (const uint8_t*)db2, (A2*)t8g2));
     size_t ne16 = (size_t)5 * 16 * 65536;
-    RC(ensure(c, c->tab16_g1, ne16 * sizeof(A1)));
-    RC(ensure(c, c->tab16_g2, ne16 * sizeof(A2)));
-    RC(launch(c, "k_build_tables16.g1", k_build_tables16<C, F1>, ne16 / 16, 64, 5, (const A1*)c->tab_g1.p, (A1*)c->tab16_g1.p));
-    RC(launch(c, "k_build_tables16.g2", k_build_tables16<C, F2>, ne16 / 16, 64, 5, (const A2*)c->tab_g2.p, (A2*)c->tab16_g2.p));
+    RC(ensure(c, tb->tab16_g1, ne16 * sizeof(A1)));
+    RC(ensure(c, tb->tab16_g2, ne16 * sizeof(A2)));
+    RC(launch(c, "k_build_tables16.g1", k_build_tables16<C, F1>, ne16 / 16, 64, 5, (const A1*)t8g1, (A1*)tb->tab16_g1.p));
+    RC(launch(c, "k_build_tables16.g2", k_build_tables16<C, F2>, ne16 / 16, 64, 5, (const A2*)t8g2, (A2*)tb->tab16_g2.p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+      std::lock_guard<std::mutex> lk(g_tables_mu);
+      g_tables.push_back(tb);
+    }
     c->have_crs = true;
     return GS_OK;
   }
@@ -606,7 +697,7 @@ template <class C> struct Impl {
       outs.stride[0] = (uint32_t)(m * Z::COM1);
       outs.base[1] = (uint8_t*)theta;
       outs.stride[1] = (uint32_t)(ky * Z::COM1);
-      RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs,
+      RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs,
                           ov ? c->side[1] : nullptr, c->sev[1], c->sev[2], pair_reds ? &red1 : nullptr)));
     }
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
@@ -629,7 +720,7 @@ template <class C> struct Impl {
       outs.base[1] = (uint8_t*)pi;
       outs.stride[1] = (uint32_t)(kx * Z::COM2);
       if (ov) c->cur = c->side[0];  // the whole G2 side runs beside the G1 side
-      RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tab16_g2.p, outs,
+      RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tabs->tab16_g2.p, outs,
                           ov ? c->side[2] : nullptr, c->sev[3], c->sev[4], pair_reds ? &red2 : nullptr)));
       if (ov) {
         hipEventRecord(c->sev[5], c->side[0]);
@@ -704,7 +795,7 @@ template <class C> struct Impl {
   // P arrays: 0 PA scratch, 1 xcoms, 2 crs G1 consts, 3 theta
   // Q arrays: 0 ycoms, 1 B, 2 crs G2 consts, 3 pi, 4 target (MSMEG2)
   static void build_verify(VerifyPlan& vp, int curve, int ty, int m, int n, const PoolMap& pm, double budget, bool twin,
-                           int tm) {
+                           int tm, bool lt) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
     int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     // ---- G1-side points: PA_j.a = map_a_j.a + sum_i Gamma_ij c_i.a ;  PB.a = sum_i b_i c_i.a - lin_t
@@ -767,7 +858,7 @@ template <class C> struct Impl {
       for (int l = 0; l < ky; l++) add_pair(pr, 3, 2 * l + a, 1, 2, 2 * l + b);     // (-theta_l.a, v_l.b)
       if (ty == GS_MSMEG2 && b == 1) add_pair(pr, 2, 4 + a, 1, 4, 0);               // (-W1.a, t)
       int lo = (int)vp.mt.size();
-      chunk_tasks(vp.mt, pr, budget, b, !twin, mcost(curve, twin));
+      chunk_tasks(vp.mt, pr, budget, b, !twin, mcost(curve, twin), lt);
       int hi = (int)vp.mt.size();
       if (twin) {
         for (int aa = 0; aa < 2; aa++) {
@@ -815,7 +906,7 @@ template <class C> struct Impl {
         if (c->miller_twin >= 0 && tw != c->miller_twin) continue;
         for (double cand : miller_budgets(c, tw != 0)) {
           VerifyPlan tmp;
-          build_verify(tmp, c->curve, ty, m, n, pm, cand, tw != 0, 1);
+          build_verify(tmp, c->curve, ty, m, n, pm, cand, tw != 0, 1, c->line_tables);
           double cost = miller_cost(c, N, tmp.mt, tw != 0);
           if (best < 0 || cost < best) {
             best = cost;
@@ -825,7 +916,7 @@ template <class C> struct Impl {
         }
       }
     }
-    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false));
+    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false), c->line_tables);
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
@@ -846,7 +937,7 @@ template <class C> struct Impl {
       memset(&outs, 0, sizeof outs);
       outs.base[0] = (uint8_t*)pa;
       outs.stride[0] = (uint32_t)(vp.npa * Z::COM1);
-      RC((run_side<C, F1>(c, ".vg1", N, vp.g1, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs)));
+      RC((run_side<C, F1>(c, ".vg1", N, vp.g1, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs)));
     }
     // Miller
     const MillerTask* dmt;
@@ -861,7 +952,7 @@ template <class C> struct Impl {
     parr.stride[0] = (uint32_t)(vp.npa * Z::COM1);
     parr.base[1] = (const uint8_t*)xcoms;
     parr.stride[1] = (uint32_t)(m * Z::COM1);
-    parr.base[2] = (const uint8_t*)c->crs_g1.p;
+    parr.base[2] = (const uint8_t*)c->tabs->crs_g1.p;
     parr.stride[2] = 0;
     parr.base[3] = (const uint8_t*)theta;
     parr.stride[3] = (uint32_t)(ky * Z::COM1);
@@ -869,7 +960,7 @@ template <class C> struct Impl {
     qarr.stride[0] = (uint32_t)(n * Z::COM2);
     qarr.base[1] = (const uint8_t*)B;
     qarr.stride[1] = (uint32_t)(m * Z::G2);
-    qarr.base[2] = (const uint8_t*)c->crs_g2.p;
+    qarr.base[2] = (const uint8_t*)c->tabs->crs_g2.p;
     qarr.stride[2] = 0;
     qarr.base[3] = (const uint8_t*)pi;
     qarr.stride[3] = (uint32_t)(kx * Z::COM2);
@@ -880,15 +971,15 @@ template <class C> struct Impl {
       const MCost mc = mcost(c->curve, twin);
       double pairs = 0;
       for (const MillerTask& t : vp.mt)
-        for (int q = 0; q < t.np; q++) pairs += pair_fixed(t.pr[q]) ? mc.fix / mc.var : 1.0;
+        for (int q = 0; q < t.np; q++) pairs += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix / mc.var : 1.0;
       c->work_hint = (uint64_t)((double)N * pairs);
     }
     if (twin)
       RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
-                (const Line<C>*)(g_line_tables ? c->line_tab.p : nullptr)));
+                (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     else
       RC(launch(c, "k_miller", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
-                (const Line<C>*)(g_line_tables ? c->line_tab.p : nullptr)));
+                (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     *mpart_out = mpart;
     return GS_OK;
   }
@@ -995,7 +1086,7 @@ template <class C> struct Impl {
       memset(&outs, 0, sizeof outs);
       outs.base[0] = (uint8_t*)s1;
       outs.stride[0] = (uint32_t)(n1 * Z::COM1);
-      RC((run_side<C, F1>(c, ".r1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs)));
+      RC((run_side<C, F1>(c, ".r1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs)));
     }
     // ---- pass 2: elements 0..n-1 = P'_j, then [PB'] , U'_k (kx), [W1'] (MSMEG2)
     int iPB = n, iU = n + (yg ? 0 : 1), iW = iU + kx, n2 = iW + (ty == GS_MSMEG2 ? 1 : 0);
@@ -1052,7 +1143,7 @@ template <class C> struct Impl {
       memset(&outs, 0, sizeof outs);
       outs.base[0] = (uint8_t*)s2;
       outs.stride[0] = (uint32_t)(n2 * Z::COM1);
-      RC((run_side<C, F1>(c, ".r2", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tab16_g1.p, outs)));
+      RC((run_side<C, F1>(c, ".r2", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs)));
     }
     // ---- Miller: every G2 argument once.  P arrays: 0 = S2, 1 = S1.  Q arrays: 0 ycoms, 1 B, 2 crs, 3 pi, 4 target
     std::vector<PairRef> pr;
@@ -1073,7 +1164,7 @@ template <class C> struct Impl {
       double best = -1;
       for (double cand : miller_budgets(c, false)) {
         std::vector<MillerTask> tmp;
-        chunk_tasks(tmp, pr, cand, 0, true, mcost(c->curve, false));
+        chunk_tasks(tmp, pr, cand, 0, true, mcost(c->curve, false), c->line_tables);
         double cost = miller_cost(c, N, tmp, false);
         if (best < 0 || cost < best) {
           best = cost;
@@ -1099,7 +1190,7 @@ template <class C> struct Impl {
     qarr.stride[0] = (uint32_t)(n * Z::COM2);
     qarr.base[1] = (const uint8_t*)B;
     qarr.stride[1] = (uint32_t)(m * Z::G2);
-    qarr.base[2] = (const uint8_t*)c->crs_g2.p;
+    qarr.base[2] = (const uint8_t*)c->tabs->crs_g2.p;
     qarr.base[3] = (const uint8_t*)pi;
     qarr.stride[3] = (uint32_t)(kx * Z::COM2);
     qarr.base[4] = (const uint8_t*)target;
@@ -1108,11 +1199,11 @@ template <class C> struct Impl {
       const MCost mc = mcost(c->curve, false);
       double pairs = 0;
       for (const MillerTask& t : mt)
-        for (int q = 0; q < t.np; q++) pairs += pair_fixed(t.pr[q]) ? mc.fix / mc.var : 1.0;
+        for (int q = 0; q < t.np; q++) pairs += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix / mc.var : 1.0;
       c->work_hint = (uint64_t)((double)N * pairs);
     }
     RC(launch(c, "k_miller.rlc", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 1,
-              (const Line<C>*)(g_line_tables ? c->line_tab.p : nullptr)));
+              (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     uint8_t* a = (uint8_t*)acc;
     RC(gt_product(c, N * ntask, (GT*)mpart, (GT*)tmp, a));
     if (ty == GS_PPE) {
@@ -1247,6 +1338,38 @@ static int left_mul_impl(gs_ctx* c, int rows, int k, const void* lhs, const void
   return st.back(out, dout, (size_t)rows * com);
 }
 
+// Matrix<Fr> product through the prover's own scalar-preparation kernel: with R = lhs^T (inner x rows) and
+// Gamma = rhs (inner x cols), Psi = R^T Gamma is lhs * rhs (prove.rs:133; the reference's Mat::right_mul / left_mul on
+// Matrix<Fr>, data_structures.rs:824-912).  Shapes with inner * cols >= 1024 take the one-lane-per-output kernel.
+template <class C> static int fr_matmul_impl(gs_ctx* c, int rows, int inner, int cols, const void* lhs, const void* rhs, void* out) {
+  typedef Fr<C> S;
+  std::vector<uint8_t> rt((size_t)inner * rows * sizeof(S));
+  const uint8_t* a = (const uint8_t*)lhs;
+  for (int k = 0; k < rows; k++)
+    for (int i = 0; i < inner; i++) memcpy(&rt[((size_t)i * rows + k) * sizeof(S)], a + ((size_t)k * inner + i) * sizeof(S), sizeof(S));
+  HostStage st(c);
+  void *dR, *dG, *dout;
+  RC(st.in(rt.data(), rt.size(), &dR));
+  RC(st.in(rhs, (size_t)inner * cols * sizeof(S), &dG));
+  RC(st.out(out, (size_t)rows * cols * sizeof(S), &dout));
+  const int m = inner, n = cols, kx = rows, ky = 0;
+  PoolMap pm = Impl<C>::prove_pool(m, n, kx, ky);
+  void* pool;
+  RC(scratch(c, "frmm.pool", (size_t)pm.total * sizeof(S), &pool));
+  if (wide_prep(m, n)) {
+    int W = m * kx + n * ky + ky * kx + m + n + kx * n + ky * m;
+    RC(launch(c, "k_prep_prove.a", k_prep_prove_wide_a<C>, (size_t)W, 64, (size_t)W, W, m, n, kx, ky, (const S*)dG,
+              (const S*)dR, (const S*)dR, (const S*)dR, (const S*)nullptr, (const S*)nullptr, pm, (S*)pool));
+  } else {
+    RC(launch(c, "k_prep_prove", k_prep_prove<C>, 1, 64, (size_t)1, m, n, kx, ky, (const S*)dG, (const S*)dR,
+              (const S*)dR, (const S*)dR, (const S*)nullptr, (const S*)nullptr, (const S*)nullptr, (const S*)nullptr, pm,
+              (S*)pool));
+  }
+  size_t cnt = (size_t)rows * cols;
+  RC(launch(c, "k_fr_to_mont", k_fr_to_mont<C>, cnt, 64, cnt, (const S*)pool + pm.PSI, (S*)dout));
+  return st.back(out, dout, cnt * sizeof(S));
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -1340,20 +1463,22 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
     c->simd_slots = 4 * (size_t)cus;
+  // developer overrides of the planner, documented in include/gs_amd.h next to gs_set_option (which is the API)
   if (const char* e = getenv("GS_COOP_FE")) c->coop_fe = atoi(e);
   if (const char* e = getenv("GS_MILLER_CH")) c->miller_ch = atoi(e);
   if (const char* e = getenv("GS_MILLER_TWIN")) c->miller_twin = atoi(e);
-  if (const char* e = getenv("GS_LINE_TABLES")) g_line_tables = atoi(e) != 0;
+  if (const char* e = getenv("GS_LINE_TABLES")) c->line_tables = atoi(e) != 0;
   if (const char* e = getenv("GS_VAR_TM")) c->var_tm = atoi(e);
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return GS_ERR_DEVICE;
   }
-  if (const char* e = getenv("GS_OVERLAP")) c->overlap = atoi(e) != 0;
   for (int i = 0; i < 3 && c->overlap; i++)
     if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess) c->overlap = false;
   for (int i = 0; i < 6 && c->overlap; i++)
     if (hipEventCreateWithFlags(&c->sev[i], hipEventDisableTiming) != hipSuccess) c->overlap = false;
+  if (!c->overlap) c->side[0] = nullptr;
+  if (const char* e = getenv("GS_OVERLAP")) c->overlap = c->overlap && atoi(e) != 0;
   *out = c;
   return GS_OK;
 }
@@ -1364,8 +1489,11 @@ void gs_ctx_destroy(gs_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& kv : c->scratch)
     if (kv.second.p) hipFree(kv.second.p);
-  for (DevBuf* b : {&c->crs_g1, &c->crs_g2, &c->tab_g1, &c->tab_g2, &c->tab16_g1, &c->tab16_g2, &c->line_tab})
-    if (b->p) hipFree(b->p);
+  for (hipStream_t st : c->side)
+    if (st) hipStreamSynchronize(st);
+  for (auto& kv : c->plans)
+    if (kv.second.dev.p) hipFree(kv.second.dev.p);
+  c->tabs.reset();  // the CRS tables go with their last context
   for (hipStream_t st : c->side)
     if (st) hipStreamDestroy(st);
   for (hipEvent_t ev : c->sev)
@@ -1378,6 +1506,30 @@ void gs_ctx_destroy(gs_ctx* c) {
 int gs_set_stream(gs_ctx* c, void* s) {
   if (!c) return GS_ERR_ARG;
   c->stream = (hipStream_t)s;
+  return GS_OK;
+}
+int gs_set_option(gs_ctx* c, const char* key, int value) {
+  if (!c || !key) return GS_ERR_ARG;
+  std::string k(key);
+  if (k == "miller_twin") {
+    if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "miller_twin: -1 (planned), 0, 1");
+    c->miller_twin = value;
+  } else if (k == "miller_ch") {
+    if (value < 0 || value > MILLER_CH) return fail(c, GS_ERR_ARG, "miller_ch: 0 (planned) .. 6");
+    c->miller_ch = value;
+  } else if (k == "var_tm") {
+    if (value < 0 || value > 8) return fail(c, GS_ERR_ARG, "var_tm: 0 (planned) .. 8");
+    c->var_tm = value;
+  } else if (k == "coop_fe") {
+    if (value < 0 || value > 2) return fail(c, GS_ERR_ARG, "coop_fe: 0 never, 1 planned, 2 always");
+    c->coop_fe = value;
+  } else if (k == "line_tables") {
+    c->line_tables = value != 0;
+  } else if (k == "overlap") {
+    c->overlap = value != 0 && c->side[0] != nullptr;
+  } else {
+    return fail(c, GS_ERR_ARG, "unknown option");
+  }
   return GS_OK;
 }
 int gs_sync(gs_ctx* c) {
@@ -1473,8 +1625,8 @@ int gs_crs_generate_hiding(gs_ctx* c, const void* p1, const void* p2, const void
     if (n == 0) return GS_OK;                                                                              \
     if (!v || !r || !out) return GS_ERR_ARG;                                                               \
     if (c->curve == 0)                                                                                     \
-      return Impl<Bls12_381>::commit<FT<Bls12_381>>(c, n, GROUP, v, r, out, (const Aff<FT<Bls12_381>>*)c->TAB.p, TAG); \
-    return Impl<Bn254>::commit<FT<Bn254>>(c, n, GROUP, v, r, out, (const Aff<FT<Bn254>>*)c->TAB.p, TAG);   \
+      return Impl<Bls12_381>::commit<FT<Bls12_381>>(c, n, GROUP, v, r, out, (const Aff<FT<Bls12_381>>*)c->tabs->TAB.p, TAG); \
+    return Impl<Bn254>::commit<FT<Bn254>>(c, n, GROUP, v, r, out, (const Aff<FT<Bn254>>*)c->tabs->TAB.p, TAG);   \
   }
 COMMIT_DEV(gs_commit_g1_dev, Fq, true, tab16_g1, ".cg1")
 COMMIT_DEV(gs_commit_g2_dev, Fp2, true, tab16_g2, ".cg2")
@@ -1696,6 +1848,15 @@ int gs_mat_left_mul_com2(gs_ctx* c, int rows, int k, const void* lhs, const void
   return left_mul_impl<Bn254, Fp2<Bn254>>(c, rows, k, lhs, col, out);
 }
 
+int gs_fr_matmul(gs_ctx* c, int rows, int inner, int cols, const void* lhs, const void* rhs, void* out) {
+  RC(check_ctx(c, false));
+  if (rows <= 0 || inner <= 0 || cols <= 0) return GS_OK;  // empty product
+  if (!lhs || !rhs || !out) return fail(c, GS_ERR_ARG, "null pointer");
+  if (rows > 4096 || inner > 4096 || cols > 4096) return fail(c, GS_ERR_SHAPE, "matrix too large");
+  if (c->curve == 0) return fr_matmul_impl<Bls12_381>(c, rows, inner, cols, lhs, rhs, out);
+  return fr_matmul_impl<Bn254>(c, rows, inner, cols, lhs, rhs, out);
+}
+
 // ---- batched (RLC) verifier ---------------------------------------------------------
 int gs_verify_batch_rlc_dev(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
                             const void* target, const void* xcoms, const void* ycoms, const void* pi,
@@ -1717,6 +1878,9 @@ int gs_verify_batch_rlc(gs_ctx* c, int ty, size_t N, int m, int n, const void* A
   int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
   size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
   size_t st_ = ty == GS_PPE ? 12 * fq : ty == GS_MSMEG1 ? 2 * fq : ty == GS_MSMEG2 ? 4 * fq : SZ_FR;
+  if (!rho) return fail(c, GS_ERR_ARG, "null pointer");
+  for (size_t i = 0; i < 4 * N; i++)  // a zero exponent drops its cell equation from the combined check
+    if (rho[i] == 0) return fail(c, GS_ERR_ARG, "rho must be non-zero (see the rho contract in gs_amd.h)");
   HostStage st(c);
   void *dA, *dB, *dG, *dt, *dxc, *dyc, *dpi, *dth, *drho, *dacc;
   std::vector<uint8_t> hacc(2 * 12 * fq);

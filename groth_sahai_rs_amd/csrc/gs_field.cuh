@@ -12,10 +12,15 @@
 #pragma once
 #include <stdint.h>
 
+// GS_FN_ATTR: optional attribute for every out-of-line device function (experiments: e.g.
+// -DGS_FN_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' builds them for two waves per SIMD)
+#ifndef GS_FN_ATTR
+#define GS_FN_ATTR
+#endif
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GS_HD __host__ __device__ __forceinline__
-#define GS_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define GS_HD_NOINLINE __host__ __device__ __attribute__((noinline)) GS_FN_ATTR
 #else
 #define GS_HD inline __attribute__((always_inline))
 #define GS_HD_NOINLINE __attribute__((noinline))

@@ -338,6 +338,14 @@ __global__ void __launch_bounds__(64, GS_WPE)
   out[e * out_stride + i] = from_mont(in[g]);
 }
 
+// canonical -> Montgomery boundary form (gs_fr_matmul hands the prover's canonical products back as Fr values)
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE) k_fr_to_mont(size_t total, const Fr<C>* in, Fr<C>* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  out[g] = to_mont(in[g]);
+}
+
 // Fr preparation for verify: Gamma (and scalar constants / target) -> canonical
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE) k_prep_verify(size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as,

@@ -318,6 +318,7 @@ GS_HD_NOINLINE bool wire_decode_point(Aff<F>& p, const uint8_t* in, bool compres
     inf = fb & 0x40;
     largest = fb & 0x20;
     if (!compressed && largest) return false;
+    if (inf && largest) return false;  // ark-bls12-381 EncodingFlags: the sort flag never accompanies infinity
   } else {
     mask = 0xC0;
     inf = fb & 0x40;
@@ -341,7 +342,10 @@ GS_HD_NOINLINE bool wire_decode_point(Aff<F>& p, const uint8_t* in, bool compres
     }
   }
   if (!canon) return false;
-  if (inf) return zero;  // the identity is all-zero coordinates plus the flag
+  // The identity is all-zero coordinates plus the flag.  Deliberately STRICTER than ark-bls12-381, which returns the
+  // identity as soon as it sees the infinity flag and ignores the payload [ark-mem]: only the one encoding arkworks'
+  // own serialiser produces is accepted, so no second byte string decodes to the same element (include/gs_amd.h).
+  if (inf) return zero;
   F x, y;
   coord_from_words<C>(x, xw);
   F rhs = curve_rhs<C>(x);

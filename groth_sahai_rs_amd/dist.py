@@ -20,11 +20,16 @@ def shard_range(n_total, rank, world):
 
 
 def allreduce_failures(n_failed_local, device=None):
-    """Total number of rejected proofs over all ranks (0 => everything verified)."""
+    """Total number of rejected proofs over all ranks (0 => everything verified): the rank-combined verdict of the
+    exact verifier.  `n_failed_local` is an int or a 0-d tensor (e.g. ``(ok == 0).sum()`` still on the GPU: no host
+    round trip before the collective); `device` is where the collective runs (the GPU for RCCL, "cpu" for gloo)."""
     import torch
     import torch.distributed as dist
 
-    t = torch.tensor([int(n_failed_local)], dtype=torch.int64, device=device)
+    if torch.is_tensor(n_failed_local):
+        t = n_failed_local.to(dtype=torch.int64, device=device).reshape(1)
+    else:
+        t = torch.tensor([int(n_failed_local)], dtype=torch.int64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())

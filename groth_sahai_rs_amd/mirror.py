@@ -152,6 +152,12 @@ class _Equation:
     def get_type(self):
         return self.TYPE
 
+    def _check_statement_shape(self, m, n):
+        """a_consts pair with the n Y variables, b_consts with the m X variables, Gamma is m x n."""
+        assert len(self.a_consts) == n, "a_consts.len() == yvars.len()"
+        assert len(self.b_consts) == m, "b_consts.len() == xvars.len()"
+        assert len(self.gamma) == m and all(len(row) == n for row in self.gamma), "gamma is m x n"
+
     # -- Provable ---------------------------------------------------------
     def _kxky(self):
         return (2 if self.TYPE in (GS_PPE, GS_MSMEG1) else 1), (2 if self.TYPE in (GS_PPE, GS_MSMEG2) else 1)
@@ -172,6 +178,8 @@ class _Equation:
         assert len(self.gamma[0]) == len(ycoms.rand)
         assert len(ycoms.rand[0]) == ky
         m, n = len(xvars), len(yvars)
+        self._check_statement_shape(m, n)
+        assert all(len(r) == kx for r in xcoms.rand) and all(len(r) == ky for r in ycoms.rand)
         T = [[rng.fr() for _ in range(kx)] for _ in range(ky)]
         out = crs.engine.prove_batch(self.TYPE, 1, m, n, _cat(xvars, 0), _cat(yvars, 0), _cat(self.a_consts, 0),
                                      _cat(self.b_consts, 0), _flat_mat(self.gamma), _flat_mat(xcoms.rand),
@@ -186,6 +194,12 @@ class _Equation:
         assert self.get_type() == com_proof.equ_proofs[0].equ_type
         pf = com_proof.equ_proofs[0]
         m, n = len(com_proof.xcoms.coms), len(com_proof.ycoms.coms)
+        # proof lengths come from the wire: check them where the reference panics (pairing_sum / left_mul,
+        # data_structures.rs:495,705) instead of letting the C ABI read past a short buffer
+        kx, ky = self._kxky()
+        assert m >= 1 and n >= 1
+        self._check_statement_shape(m, n)
+        assert len(pf.pi) == kx and len(pf.theta) == ky
         ok = crs.engine.verify_batch(self.TYPE, 1, m, n, _cat(self.a_consts, 0), _cat(self.b_consts, 0),
                                      _flat_mat(self.gamma), np.asarray(self.target, dtype=np.uint64),
                                      _cat(com_proof.xcoms.coms, 0), _cat(com_proof.ycoms.coms, 0), _cat(pf.pi, 0),

@@ -213,10 +213,15 @@ class Workload:
         """batched verifier: ONE final exponentiation for the batch; returns the accumulator pair (device)"""
         import torch
 
-        if not hasattr(self, "rho"):
-            g = torch.Generator(device="cpu").manual_seed(20241220)
-            rho = torch.randint(1, 2**62, (self.N * 4,), generator=g, dtype=torch.int64)
-            self.rho = rho.to(self.xcoms.device)
+        import os
+
+        import numpy as np
+
+        # the rho contract of gs_amd.h: fresh per call, from the OS CSPRNG, non-zero, drawn after the proofs exist
+        raw = np.frombuffer(os.urandom(self.N * 32), dtype=np.uint64).copy()
+        raw[raw == 0] = 1
+        self.rho = torch.from_numpy(raw.view(np.int64)).to(self.xcoms.device)
+        if not hasattr(self, "acc"):
             self.acc = torch.empty(2 * self.eng.GT, dtype=torch.uint8, device=self.xcoms.device)
         self.eng.verify_batch_rlc_dev(self.ty, self.N, self.m, self.n, self.A, self.B, self.Gamma, self.target,
                                       self.xcoms, self.ycoms, self.pi, self.theta, self.rho, self.acc)

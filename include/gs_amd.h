@@ -5,8 +5,8 @@
  * implementing its public traits would bind (INTEGRATION.md shows the shim):
  *
  *   gs_commit_*            <- src/prover/commit.rs:59-256  (commit_G1, batch_commit_G1, ... scalar_to_B2)
- *   gs_prove_batch         <- src/prover/prove.rs:92-171,195-274,298-379,409-488  (Provable::prove)
- *   gs_commit_and_prove_batch <- src/prover/prove.rs:72-90,175-193,278-296,383-408
+ *   gs_prove_batch         <- src/prover/prove.rs:92-171,195-274,298-379,409-488  (Provable::prove), and with
+ *                             xcoms/ycoms != NULL src/prover/prove.rs:72-90,175-193,278-296,383-408 (commit_and_prove)
  *   gs_verify_batch        <- src/verifier.rs:23-157       (Verifiable::verify, exact semantics, bool per equation)
  *   gs_verify_batch_rlc    <- (new) batched pairing-product check, one final exponentiation per batch
  *   gs_mat_left_mul_com1/2 <- src/data_structures.rs:696-742 (Mat::left_mul on Matrix<Com1/Com2>)
@@ -38,7 +38,12 @@
  * un-suffixed ones take HOST pointers, stage through device memory and return
  * after the results are back.  A gs_ctx is bound to one GPU and may be used from
  * one host thread at a time.  Points must lie in the prime-order subgroups (as
- * arkworks' deserialisation guarantees); like the reference, nothing is checked.
+ * arkworks' deserialisation guarantees).  Nothing is checked on the compute entry
+ * points, and -- UNLIKE the reference, whose plain double-and-add works on any curve
+ * point -- results for on-curve points OUTSIDE the subgroups are UNDEFINED here
+ * (scalar multiplications use the GLV / psi-GLS endomorphisms, which act as a
+ * scalar only on the r-torsion).  Decode untrusted bytes with gs_wire_decode_*
+ * (validate = 1) before handing points to the *_dev calls.
  *
  * Errors: the reference panics on shape mismatch (assert_eq!, e.g.
  * src/prover/prove.rs:106-113); here every call returns a status and a shim
@@ -62,7 +67,18 @@ enum { GS_OK = 0, GS_ERR_SHAPE = 1, GS_ERR_DEVICE = 2, GS_ERR_ARG = 3, GS_ERR_NO
 /* ---- context ---------------------------------------------------------- */
 int gs_ctx_create(int curve_id, int device_ordinal, gs_ctx** out);
 void gs_ctx_destroy(gs_ctx* ctx);
+/* Several GPUs: one context per device ordinal, sharded by the caller, or gs_ctx_create_multi below. */
 int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default stream */
+/* Planner overrides (results never change, only which kernel shapes run; tests force every shape through them):
+ *   "miller_twin"  -1 planned | 0 one accumulator per Miller lane | 1 two (lines of Q shared by both G1 partners)
+ *   "miller_ch"     0 planned | 1..6 pairs (triples) per Miller lane
+ *   "var_tm"        0 planned | 1..8 variable-base terms per Straus lane
+ *   "coop_fe"       0 one lane per final exponentiation | 1 planned | 2 always the 3-lane cooperative form
+ *   "line_tables"   1 CRS G2 arguments read precomputed Miller lines | 0 they are stepped like any other point
+ *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream
+ * The same knobs are read ONCE at gs_ctx_create from the environment for experiments without recompiling the caller:
+ * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP (same values).  Unset = planned. */
+int gs_set_option(gs_ctx* ctx, const char* key, int value);
 int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the context's stream */
 const char* gs_last_error(gs_ctx* ctx);
 const char* gs_version(void);
@@ -70,8 +86,10 @@ const char* gs_version(void);
 int gs_sizes(int curve_id, size_t out[6]);
 
 /* CRS (host pointer): uploads, derives W1 = u[1]+(O,g1), W2 = v[1]+(O,g2) and
- * builds the fixed-base window tables (16-bit windows: 1.8 GB of device memory per context) and the Miller
- * line tables of its G2 elements on the device. */
+ * builds the fixed-base window tables (16-bit windows: 1.8 GB of device memory) and the Miller
+ * line tables of its G2 elements on the device.  The tables are immutable and SHARED: every context of the process
+ * that installs the same CRS bytes on the same device uses one copy (reference-counted; freed with the last context),
+ * so a pool of worker contexts costs 1.8 GB per device, not per worker. */
 int gs_set_crs(gs_ctx* ctx, const void* crs_host);
 
 /* CRS of the reference's shape (src/generator.rs:81-118, binding key :48-60) from caller-drawn values:
@@ -116,7 +134,14 @@ int gs_verify_batch(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A
                     const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
                     uint8_t* ok);
 /* Batched pairing-product check: random linear combination of all 4N cell
- * equations with caller-supplied 64-bit exponents rho[N][4] (device/host u64),
+ * equations with caller-supplied 64-bit exponents rho[N][4] (device/host u64).
+ * RHO CONTRACT (soundness rests on it): every rho is drawn from a CSPRNG, fresh for every call, NON-ZERO, secret
+ * until the verdict is out, and drawn AFTER the commitments and proofs of the batch are fixed.  A predictable or
+ * reused rho lets a prover craft a batch that passes the combined check while single equations fail; the soundness
+ * error is 2^-64 per batch for honest-size exponents.  The host entry rejects rho == 0 (GS_ERR_ARG); the _dev entry
+ * cannot look.  PPE targets are raised to rho WITHOUT a subgroup check: a target outside the order-r subgroup of GT
+ * (impossible for a decoded, validated PairingOutput, gs_wire_decode_gt validate = 1) is the caller's to exclude.
+ * The exact entry points above have no such contract.
  * one final exponentiation for the whole batch.  *ok_all = 1 iff the combined
  * check passes; acc (may be NULL for the host entry) receives the accumulator PAIR
  * (2 GT): acc[0] = prod Miller(e,cell)^rho (un-exponentiated), acc[1] = prod t_e^rho
@@ -138,6 +163,10 @@ int gs_mat_left_mul_com1(gs_ctx*, int rows, int k, const void* lhs_fr, const voi
 int gs_mat_left_mul_com2(gs_ctx*, int rows, int k, const void* lhs_fr, const void* col_com2, void* out_com2);
 /* ComT::pairing_sum(x[0..k), y[0..k)) -> 4 GT cells (00,01,10,11)   (data_structures.rs:494-502) */
 int gs_pairing_sum(gs_ctx*, int k, const void* x_com1, const void* y_com2, void* out_comt);
+/* Matrix<Fr> product out = lhs (rows x inner) * rhs (inner x cols), row-major Montgomery Fr, host pointers, computed by
+ * the prover's scalar-preparation kernels (Psi = R^T Gamma, prove.rs:133): the reference's Mat::right_mul / left_mul on
+ * Matrix<Fr> (data_structures.rs:824-912) and the hook its matrix KATs (:1726-1947) run through. */
+int gs_fr_matmul(gs_ctx*, int rows, int inner, int cols, const void* lhs_fr, const void* rhs_fr, void* out_fr);
 /* batch helpers: out[i] = k[i] * P[i] (P broadcast if p_stride == 0), E::multi_pairing per row */
 int gs_g1_mul_batch(gs_ctx*, size_t count, const void* p_g1, int p_broadcast, const void* k_fr, void* out_g1);
 int gs_g2_mul_batch(gs_ctx*, size_t count, const void* p_g2, int p_broadcast, const void* k_fr, void* out_g2);
@@ -158,7 +187,9 @@ int gs_gt_pow_batch_dev(gs_ctx*, size_t count, const void* base_gt_dev, const vo
  * include/gs_amd.hpp, groth_sahai_rs_amd/wire.py.  Host pointers.  decode: ok[i] = 1 iff element i is a
  * well-formed encoding (canonical coordinates, consistent flags, on the curve) and, with validate != 0,
  * passes the r-torsion check of ark-serialize's Validate::Yes; rejected elements decode to the identity
- * (points) / zero.  sizes: out[0..5] = G1 compressed, G1 uncompressed, G2 compressed, G2 uncompressed, Fr, GT. */
+ * (points) / zero.  The identity has exactly ONE accepted encoding (infinity flag, all-zero payload, no sort flag):
+ * ark-bls12-381 ignores the payload once it sees the infinity flag, this decoder does not (stricter; arkworks'
+ * own serialiser never produces the other byte strings).  sizes: out[0..5] = G1 compressed, G1 uncompressed, G2 compressed, G2 uncompressed, Fr, GT. */
 int gs_wire_sizes(int curve_id, size_t out[6]);
 int gs_wire_encode_g1(gs_ctx*, size_t n, int compressed, const void* pts_g1, uint8_t* out);
 int gs_wire_encode_g2(gs_ctx*, size_t n, int compressed, const void* pts_g2, uint8_t* out);

@@ -237,6 +237,14 @@ template <class A1, class A2, class AT, EquType TYPE> struct Equation {
 
   EquType get_type() const { return TYPE; }
 
+  // a_consts pair with the n Y variables, b_consts with the m X variables, Gamma is m x n
+  void check_statement_shape(size_t m, size_t n) const {
+    assert_eq(a_consts.size(), n, "a_consts.len() == yvars.len()");
+    assert_eq(b_consts.size(), m, "b_consts.len() == xvars.len()");
+    assert_eq(gamma.size(), m, "gamma.len() == xvars.len()");
+    for (const auto& row : gamma) assert_eq(row.size(), n, "gamma[i].len() == yvars.len()");
+  }
+
   template <class Rng>
   CProof commit_and_prove(const std::vector<A1>& xvars, const std::vector<A2>& yvars, const CRS& crs, Rng& rng) const {
     Commit1 xcoms = batch_commit_x(xvars, crs, rng);
@@ -258,10 +266,23 @@ template <class A1, class A2, class AT, EquType TYPE> struct Equation {
     assert_eq(gamma[0].size(), ycoms.rand.size(), "gamma[0].len() == ycoms.rand.len()");
     assert_eq(ycoms.rand[0].size(), KY, "ycoms.rand[0].len()");
     size_t m = xvars.size(), n = yvars.size();
+    // what the reference's left_mul / pairing_sum would panic on later (data_structures.rs:495,705): every row of
+    // Gamma has n entries, one constant per variable of the other side, uniform randomness rows
+    check_statement_shape(m, n);
+    for (const auto& r : xcoms.rand) assert_eq(r.size(), KX, "xcoms.rand[i].len()");
+    for (const auto& r : ycoms.rand) assert_eq(r.size(), KY, "ycoms.rand[j].len()");
     Matrix<Fr> T = detail::draw(rng, KY, KX);
     Bytes X = cat(xvars), Y = cat(yvars), A = cat(a_consts), B = cat(b_consts), G = cat(gamma), R = cat(xcoms.rand),
           S = cat(ycoms.rand), Tb = cat(T);
     const Ctx& cx = *crs.ctx;
+    const size_t sx = is_scalar<A1>::value ? cx.sz[1] : cx.sz[2], sy = is_scalar<A2>::value ? cx.sz[1] : cx.sz[3];
+    assert_eq(X.size(), m * sx, "xvars bytes");
+    assert_eq(Y.size(), n * sy, "yvars bytes");
+    assert_eq(A.size(), n * sx, "a_consts bytes");
+    assert_eq(B.size(), m * sy, "b_consts bytes");
+    assert_eq(G.size(), m * n * cx.sz[1], "gamma bytes");
+    assert_eq(R.size(), m * KX * cx.sz[1], "xcoms.rand bytes");
+    assert_eq(S.size(), n * KY * cx.sz[1], "ycoms.rand bytes");
     Bytes pi(KX * 2 * cx.sz[3]), th(KY * 2 * cx.sz[2]);
     cx.chk(gs_prove_batch(cx.c, (int)TYPE, 1, (int)m, (int)n, X.data(), Y.data(), A.data(), B.data(), G.data(),
                           R.data(), S.data(), Tb.data(), nullptr, nullptr, pi.data(), th.data()));
@@ -276,10 +297,28 @@ template <class A1, class A2, class AT, EquType TYPE> struct Equation {
     if (com_proof.equ_proofs[0].equ_type != TYPE) throw Panic("assertion failed: equation type matches the proof's");
     const EquProof& pf = com_proof.equ_proofs[0];
     size_t m = com_proof.xcoms.coms.size(), n = com_proof.ycoms.coms.size();
+    // Lengths come straight from the wire (Vec<_> prefixes): everything the C ABI will index is checked HERE, where
+    // the reference panics in pairing_sum / left_mul (data_structures.rs:495,705) -- never read past a short buffer.
+    if (m == 0 || n == 0) throw Panic("index out of bounds: empty commitment list");
+    check_statement_shape(m, n);
+    assert_eq(pf.pi.size(), KX, "pi.len()");
+    assert_eq(pf.theta.size(), KY, "theta.len()");
+    const Ctx& cxs = *crs.ctx;
+    const size_t tsz = TYPE == EquType::PairingProduct ? cxs.sz[4] : TYPE == EquType::MultiScalarG1 ? cxs.sz[2]
+                       : TYPE == EquType::MultiScalarG2 ? cxs.sz[3] : cxs.sz[1];
+    assert_eq(target.v.size(), tsz, "target size");
     Bytes A = cat(a_consts), B = cat(b_consts), G = cat(gamma), xc = cat(com_proof.xcoms.coms),
           yc = cat(com_proof.ycoms.coms), pi = cat(pf.pi), th = cat(pf.theta);
     uint8_t ok = 0;
     const Ctx& cx = *crs.ctx;
+    const size_t sx = is_scalar<A1>::value ? cx.sz[1] : cx.sz[2], sy = is_scalar<A2>::value ? cx.sz[1] : cx.sz[3];
+    assert_eq(A.size(), n * sx, "a_consts bytes");
+    assert_eq(B.size(), m * sy, "b_consts bytes");
+    assert_eq(G.size(), m * n * cx.sz[1], "gamma bytes");
+    assert_eq(xc.size(), m * 2 * cx.sz[2], "xcoms bytes");
+    assert_eq(yc.size(), n * 2 * cx.sz[3], "ycoms bytes");
+    assert_eq(pi.size(), KX * 2 * cx.sz[3], "pi bytes");
+    assert_eq(th.size(), KY * 2 * cx.sz[2], "theta bytes");
     cx.chk(gs_verify_batch(cx.c, (int)TYPE, 1, (int)m, (int)n, A.data(), B.data(), G.data(), target.v.data(),
                            xc.data(), yc.data(), pi.data(), th.data(), &ok));
     return ok == 1;

@@ -137,6 +137,8 @@ def dec_point(b, group, compressed, validate=True):
         inf, largest = bool(fb & 0x40), bool(fb & 0x20)
         if not compressed and largest:
             raise ValueError("sort flag on an uncompressed point")
+        if inf and largest:
+            raise ValueError("sort flag on the identity")  # ark-bls12-381 EncodingFlags::get_flags
         buf[0] &= 0x1F
         vals = [int.from_bytes(buf[i * n:(i + 1) * n], "big") for i in range(total // n)]
         xs = list(reversed(vals[:nc]))

@@ -185,6 +185,52 @@ static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const By
       threw = true;
     }
     CHECK(threw);
+    // lengths that come from the wire must panic BEFORE the C ABI reads them (the reference panics in pairing_sum /
+    // left_mul, data_structures.rs:495,705): short pi, short theta, missing constants, ragged Gamma, short target
+    auto panics = [&](const Equ& e, const CProof& p) {
+      try {
+        e.verify(p, crs);
+      } catch (const Panic&) {
+        return true;
+      }
+      return false;
+    };
+    {
+      CProof p = proof;
+      p.equ_proofs[0].pi.pop_back();
+      CHECK(panics(equ, p));
+      p = proof;
+      p.equ_proofs[0].theta.clear();
+      CHECK(panics(equ, p));
+      p = proof;
+      p.equ_proofs[0].pi[0].v.resize(p.equ_proofs[0].pi[0].v.size() / 2);
+      CHECK(panics(equ, p));
+      Equ e2 = equ;
+      e2.a_consts.pop_back();
+      CHECK(panics(e2, proof));
+      e2 = equ;
+      e2.b_consts.push_back(e2.b_consts[0]);
+      CHECK(panics(e2, proof));
+      e2 = equ;
+      e2.gamma[0].pop_back();
+      CHECK(panics(e2, proof));
+      e2 = equ;
+      e2.target.v.resize(e2.target.v.size() - 8);
+      CHECK(panics(e2, proof));
+      p = proof;
+      p.xcoms.coms.clear();
+      CHECK(panics(equ, p));
+    }
+    threw = false;
+    try {
+      Equ e2 = equ;
+      e2.a_consts.pop_back();
+      ReplayRng r = rng_of({&T});
+      e2.prove(xvars, yvars, xcoms, ycoms, crs, r);
+    } catch (const Panic&) {
+      threw = true;
+    }
+    CHECK(threw);
   }
 }
 

@@ -132,8 +132,26 @@ def build(curve):
     out["g2_smul"] = [{"k": O.hx(k), "out": O.enc_g2(O.g2_mul(k, g2s))} for k in ks]
     a, b = rng.fr(), rng.fr()
     pa, qb = O.g1_mul(a, g1s), O.g2_mul(b, g2s)
+    # The ONE line of Rust that would pin every byte of this path to arkworks (the reference has no vectors, no
+    # Cargo.lock, and no Rust toolchain exists here): serialise the pairing of the standard generators and compare
+    # with `expected_hex` = this oracle's value in ark-serialize's form (12 Fq, 48/32 little-endian bytes each,
+    # order c0.c0.c0 .. c1.c2.c1).  Equal bytes pin arkworks' final-exponent convention (BLS12: the cube of the
+    # textbook pairing) and the limb/tower layout at once; G1/G2 outputs and verdicts are canonical regardless.
+    import gs_wire_oracle as W
+
+    e_gen = O.pairing(g1s, g2s)
+    out["pin_request"] = {
+        "status": "parity unpinned at the byte level: nothing in /root/reference holds a vector and it cannot be built here",
+        "rust": ("use ark_ec::{pairing::Pairing, AffineRepr}; use ark_serialize::CanonicalSerialize; "
+                 "let e = ark_%s::%s::pairing(<G1Affine>::generator(), <G2Affine>::generator()); "
+                 "let mut b = Vec::new(); e.serialize_compressed(&mut b).unwrap(); println!(\"{}\", hex::encode(b));")
+        % (("bls12_381", "Bls12_381") if curve.name == "bls12_381" else ("bn254", "Bn254")),
+        "crate_versions": "ark-ec ^0.5.0, ark-serialize ^0.5.0, ark-bls12-381 ^0.5.0 / ark-bn254 ^0.5.0 (Cargo.toml:15-22)",
+        "expected_hex": W.enc_gt(e_gen).hex(),
+        "also": "every G1/G2/GT value of this file can be checked the same way with serialize_compressed",
+    }
     out["pairing"] = [
-        {"p": O.enc_g1(g1s), "q": O.enc_g2(g2s), "out": O.enc_f12(O.pairing(g1s, g2s))},
+        {"p": O.enc_g1(g1s), "q": O.enc_g2(g2s), "out": O.enc_f12(e_gen)},
         {"p": O.enc_g1(pa), "q": O.enc_g2(qb), "out": O.enc_f12(O.pairing(pa, qb))},
     ]
     fa = O.pairing(pa, qb)

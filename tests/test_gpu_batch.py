@@ -16,50 +16,9 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 
 
 def _run(curve_id, cname, ty, N, m, n, sample):
-    import torch
+    from gpubatch import run_batch
 
-    import groth_sahai_rs_amd as gs
-    import gs_ref_py as ref
-    from groth_sahai_rs_amd.workload import Workload
-
-    eng = gs.Engine(curve_id, 0)
-    wl = Workload(eng, ty=ty, N=N, m=m, n=n, seed=777 + ty, corrupt_every=max(N // 4, 1))
-    wl.prove()
-    eng.sync()
-    host = lambda t: t.cpu().numpy()
-    X, Y, A, B, G, R, S, T = map(host, (wl.X, wl.Y, wl.A, wl.B, wl.Gamma, wl.R, wl.S, wl.T))
-    xc, yc, pi, th, tgt = map(host, (wl.xcoms, wl.ycoms, wl.pi, wl.theta, wl.target))
-    sh = wl.sh
-    kx, ky = sh["kx"], sh["ky"]
-    sx, sy, st = sh["sx"], sh["sy"], sh["st"]
-    cut = lambda a, e, sz: a[e * sz:(e + 1) * sz]
-    for e in sample:
-        out = ref.commit_and_prove(cname, ty, m, n, cut(X, e, m * sx), cut(Y, e, n * sy), cut(A, e, n * sx),
-                                   cut(B, e, m * sy), cut(G, e, m * n * 32), cut(R, e, m * kx * 32),
-                                   cut(S, e, n * ky * 32), cut(T, e, ky * kx * 32), wl.crs)
-        assert (out["xcoms"] == cut(xc, e, m * eng.COM1)).all(), (ty, e, "xcoms")
-        assert (out["ycoms"] == cut(yc, e, n * eng.COM2)).all(), (ty, e, "ycoms")
-        assert (out["pi"] == cut(pi, e, kx * eng.COM2)).all(), (ty, e, "pi")
-        assert (out["theta"] == cut(th, e, ky * eng.COM1)).all(), (ty, e, "theta")
-        assert ref.verify(cname, ty, m, n, cut(A, e, n * sx), cut(B, e, m * sy), cut(G, e, m * n * 32),
-                          cut(tgt, e, st), out["xcoms"], out["ycoms"], out["pi"], out["theta"], wl.crs) == 1
-    # whole batch: exact verdicts
-    wl.verify()
-    eng.sync()
-    assert wl.ok.cpu().numpy().all()
-    assert eng.gt_finalize(wl.verify_rlc().cpu().numpy()) == 1
-    bad = wl.corrupt()
-    wl.verify()
-    eng.sync()
-    ok = wl.ok.cpu().numpy()
-    assert [int(v) for v in ok] == [0 if i in set(bad) else 1 for i in range(N)]
-    assert eng.gt_finalize(wl.verify_rlc().cpu().numpy()) == 0
-    # the C oracle agrees on one corrupted proof
-    e = bad[0]
-    assert ref.verify(cname, ty, m, n, cut(A, e, n * sx), cut(B, e, m * sy), cut(G, e, m * n * 32), cut(tgt, e, st),
-                      cut(xc, e, m * eng.COM1), cut(yc, e, n * eng.COM2), cut(host(wl.pi), e, kx * eng.COM2),
-                      cut(th, e, ky * eng.COM1), wl.crs) == 0
-    eng.close()
+    run_batch(curve_id, cname, ty, N, m, n, sample)
 
 
 @pytest.mark.parametrize("ty", [0, 1, 2, 3])
@@ -108,24 +67,44 @@ def test_full_config1_batch_properties():
     eng.close()
 
 
+@pytest.mark.parametrize("launch", ["torchrun", "bare"])
 @pytest.mark.parametrize("mode", ["exact", "rlc"])
-def test_bench_two_rank_rehearsal(mode):
-    """bench.py under the driver's launch line with 2 ranks.  On a one-GPU box the ranks share cuda:0 and use gloo
-    (GS_BENCH_BACKEND): this checks the launch contract, the per-rank seeds/shards, the barrier + max-over-ranks
-    timing and -- in rlc mode -- the accumulator all-gather; the numbers themselves mean nothing."""
+def test_bench_two_rank_rehearsal(mode, launch):
+    """bench.py with 2 ranks, under the driver's launch line (torchrun) AND as the bare `python bench.py --gpus 2`, which
+    must start its own two ranks.  On a one-GPU box the ranks share cuda:0 and use gloo (GS_BENCH_BACKEND): this checks
+    the launch contract, the per-rank seeds/shards, the barrier + max-over-ranks timing, the failure-count all-reduce
+    inside the timed step (exact) and the accumulator all-gather (rlc); the numbers themselves mean nothing."""
     import json
     import subprocess
 
     env = dict(os.environ, GS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533" if mode == "exact" else "29534", os.path.join(REPO, "bench.py"),
-           "--gpus", "2", "--steps", "1", "--warmup", "1", "--log2n", "8", "--no-cpu", "--mode", mode]
+    env.pop("WORLD_SIZE", None)
+    tail = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log2n", "8", "--no-cpu",
+            "--mode", mode]
+    if launch == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29533" if mode == "exact" else "29534"] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "strong"
+    assert line["config"]["total_equations"] == 512
     assert line["value"] == pytest.approx(2 * 256 / (line["ms_per_step"] / 1e3), rel=1e-6)
     assert line["roofline"]["alu"]["frac"] > 0
+
+
+def test_bench_refuses_fewer_ranks_than_requested():
+    """--gpus 4 under a 2-rank launch is an error (exit code 3), not a silently smaller job."""
+    import subprocess
+
+    env = dict(os.environ, GS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29535", os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1",
+           "--log2n", "6", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
 
 
 @pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])

@@ -127,6 +127,47 @@ def test_shape_asserts(setup):
     assert ei.value.code == 1  # GS_ERR_SHAPE: empty variable list (reference panics indexing rand[0])
 
 
+def test_verify_rejects_malformed_lengths(setup):
+    """Proof / statement lengths come from the wire (Vec<_> prefixes).  verify must panic where the reference does
+    (pairing_sum / left_mul asserts, data_structures.rs:495,705; verifier.rs:25-26) and never hand a short buffer to
+    the C ABI: one pi element, no theta, missing constants, ragged Gamma, truncated element bytes."""
+    import copy
+
+    import groth_sahai_rs_amd as gs
+
+    c, mirror, crs = setup
+    case = c.golden["cases"][0]
+    equ, xvars, yvars = build(c, mirror, case)
+    rng = ReplayRng(c, [case["R"], case["S"], case["T"]])
+    proof = equ.commit_and_prove(xvars, yvars, crs, rng)
+    assert equ.verify(proof, crs)
+
+    def mutated(fn):
+        p = copy.deepcopy(proof)
+        fn(p)
+        return p
+
+    for fn in (lambda p: p.equ_proofs[0].pi.pop(), lambda p: p.equ_proofs[0].theta.clear(),
+               lambda p: p.xcoms.coms.clear(), lambda p: p.equ_proofs.append(p.equ_proofs[0])):
+        with pytest.raises(AssertionError):
+            equ.verify(mutated(fn), crs)
+    # truncated element bytes: caught by the ctypes layer's byte-length check (GS_ERR_SHAPE)
+    with pytest.raises(gs.GsError) as ei:
+        equ.verify(mutated(lambda p: p.equ_proofs[0].pi.__setitem__(0, p.equ_proofs[0].pi[0][:-6])), crs)
+    assert ei.value.code == 1
+    for attr, fn in (("a_consts", lambda v: v[:-1]), ("b_consts", lambda v: v + v[:1]),
+                     ("gamma", lambda g: [g[0][:-1]] + g[1:]), ("gamma", lambda g: g[:-1])):
+        e2 = copy.deepcopy(equ)
+        setattr(e2, attr, fn(getattr(e2, attr)))
+        with pytest.raises(AssertionError):
+            e2.verify(proof, crs)
+        with pytest.raises(AssertionError):
+            rng2 = ReplayRng(c, [case["T"]])
+            e2.prove(xvars, yvars, proof.xcoms, proof.ycoms, crs, rng2)
+    # nothing above poisoned the context
+    assert equ.verify(proof, crs)
+
+
 def test_generate_crs_structure(setup):
     """generator.rs:137-207: generators are non-degenerate, gt_gen = e(g1, g2), and the binding-key
     structure u[1] = t1 * u[0], v[1] = t2 * v[0] holds."""

@@ -269,3 +269,77 @@ def test_status_codes_and_empty_batches(engines):
     h = ctypes.c_void_p()
     assert lib.gs_ctx_create(5, 0, ctypes.byref(h)) == 3
     assert lib.gs_ctx_create(0, 99, ctypes.byref(h)) == 2  # GS_ERR_DEVICE
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_field_matrix_kats_on_the_prover_kernels(engines, cname):
+    """The reference's Matrix<Fr> KATs (data_structures.rs:1726-1947) on the HIP path: gs_fr_matmul runs the product
+    through k_prep_prove (Psi = R^T Gamma) -- and through the one-lane-per-output kernel for a shape past its switch.
+      [[1,2,3],[4,5,6]] * [[7..10],[11..14],[15..18]] = [[74,80,86,92],[173,188,203,218]]
+    plus a 1 x 1, a product with the identity, (r-1)-entries (wrap-around), and the C oracle on random matrices."""
+    import os
+    import sys
+
+    from gsutil import REPO
+
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gs_ref_py as ref
+
+    c, e = engines[cname]
+    mat = lambda rows: [[c.fr(v) for v in r] for r in rows]
+    dec = lambda out: [[c.fr_dec(v) for v in r] for r in out]
+    assert dec(e.fr_matmul(mat([[1, 2, 3], [4, 5, 6]]), mat([[7, 8, 9, 10], [11, 12, 13, 14], [15, 16, 17, 18]]))) == \
+        [[74, 80, 86, 92], [173, 188, 203, 218]]
+    assert dec(e.fr_matmul(mat([[6]]), mat([[7]]))) == [[42]]
+    assert dec(e.fr_matmul(mat([[1, 0], [0, 1]]), mat([[5, 6], [7, 8]]))) == [[5, 6], [7, 8]]
+    r = c.r
+    assert dec(e.fr_matmul(mat([[r - 1, r - 1]]), mat([[r - 1], [2]]))) == [[(1 - 2) % r]]
+    rng = np.random.default_rng(5)
+    for rows, inner, cols in ((2, 4, 4), (3, 5, 2), (2, 40, 33), (1, 1, 7)):  # 40 x 33 >= 1024: the wide kernel
+        rnd = lambda a, b: [[int.from_bytes(rng.bytes(40), "little") % r for _ in range(b)] for _ in range(a)]
+        A, B = rnd(rows, inner), rnd(inner, cols)
+        got = dec(e.fr_matmul(mat(A), mat(B)))
+        want = [[sum(A[i][k] * B[k][j] for k in range(inner)) % r for j in range(cols)] for i in range(rows)]
+        assert got == want
+        a = np.concatenate([c.fr(v) for row in A for v in row])
+        b = np.concatenate([c.fr(v) for row in B for v in row])
+        o = ref.fr_matmul(cname, rows, inner, cols, a, b).view(np.uint64).reshape(rows * cols, 4)
+        assert [c.fr_dec(v) for v in o] == [v for row in want for v in row]
+
+
+def test_contexts_share_crs_tables_and_rlc_rejects_zero_rho(engines):
+    """Two contexts with the same CRS on one device share the 1.8 GB of window tables (gs_set_crs); a third context
+    proving through the shared tables gives the same bytes.  gs_verify_batch_rlc refuses a zero exponent."""
+    import torch
+
+    import groth_sahai_rs_amd as gs
+    from groth_sahai_rs_amd.capi import GsError
+
+    c, e = engines["bls12_381"]
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    e2 = gs.Engine(0, 0)
+    e2.set_crs(e._crs)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 256 << 20, "a second context with the same CRS must not build its own tables"
+    case = c.golden["cases"][0]
+    X, Y = enc_side(c, 0, "x", case["xvars"]), enc_side(c, 0, "y", case["yvars"])
+    A, B = enc_side(c, 0, "x", case["a"]), enc_side(c, 0, "y", case["b"])
+    G, R, S, T = (c.fr_mat(case[k]) for k in ("gamma", "R", "S", "T"))
+    o1 = e.prove_batch(0, 1, case["m"], case["n"], X, Y, A, B, G, R, S, T)
+    o2 = e2.prove_batch(0, 1, case["m"], case["n"], X, Y, A, B, G, R, S, T)
+    assert all((o1[k] == o2[k]).all() for k in o1)
+    tgt = enc_target(c, 0, case["target"])
+    rho = np.array([3, 5, 0, 9], dtype=np.uint64)
+    with pytest.raises(GsError) as ei:
+        e2.verify_batch_rlc(0, 1, case["m"], case["n"], A, B, G, tgt, o2["xcoms"], o2["ycoms"], o2["pi"], o2["theta"], rho)
+    assert ei.value.code == 3
+    rho[2] = 7
+    ok, _ = e2.verify_batch_rlc(0, 1, case["m"], case["n"], A, B, G, tgt, o2["xcoms"], o2["ycoms"], o2["pi"],
+                                o2["theta"], rho)
+    assert ok == 1
+    e2.close()
+    # the first context still works after the second one is gone (tables are reference-counted)
+    o3 = e.prove_batch(0, 1, case["m"], case["n"], X, Y, A, B, G, R, S, T)
+    assert all((o1[k] == o3[k]).all() for k in o1)

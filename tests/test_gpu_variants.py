@@ -1,0 +1,62 @@
+"""Every kernel SHAPE the planner can pick is compared with the C oracle.
+
+The planner (csrc/gs_amd.hip: miller_cost, pick_tm, coop_fe) switches kernels with the batch size: twin-accumulator
+Miller lanes, 2..6 pairs per lane, Straus groups of 4 / 8 terms, one-lane or 3-lane final exponentiation, table-reading
+or stepping CRS pairs, side streams.  At the small N the oracle can follow, the planner alone would only ever choose
+the small-batch shapes; here every shape is FORCED through gs_set_option, all four equation types, both curves, every
+equation of the batch bit-exact (commitments, pi, theta) and verdict-exact against oracle/gs_ref.c, and the library's
+kernel profile proves that the intended kernel is the one that ran.  Reference: src/prover/prove.rs:92-171,
+src/verifier.rs:23-55."""
+import pytest
+
+from gpubatch import run_batch
+
+pytestmark = pytest.mark.gpu
+
+# name -> options; chosen so that every value of every knob occurs with both values of its neighbours
+SHAPES = {
+    "twin6_straus8_lane": dict(miller_twin=1, miller_ch=6, var_tm=8, coop_fe=0, line_tables=1, overlap=0),
+    "twin2_straus4_coop_notab": dict(miller_twin=1, miller_ch=2, var_tm=4, coop_fe=2, line_tables=0, overlap=0),
+    "twin4_straus2_lane_overlap": dict(miller_twin=1, miller_ch=4, var_tm=2, coop_fe=0, line_tables=1, overlap=1),
+    "single6_straus8_lane": dict(miller_twin=0, miller_ch=6, var_tm=8, coop_fe=0, line_tables=1, overlap=0),
+    "single1_plain_coop_notab_overlap": dict(miller_twin=0, miller_ch=1, var_tm=1, coop_fe=2, line_tables=0, overlap=1),
+    "single3_straus4_coop": dict(miller_twin=0, miller_ch=3, var_tm=4, coop_fe=2, line_tables=1, overlap=0),
+}
+
+
+def expected_kernels(ty, m, n, o):
+    xg, yg = ty in (0, 1), ty in (0, 2)
+    ex = ["k_miller.twin" if o["miller_twin"] else "k_miller", "k_final.coop" if o["coop_fe"] == 2 else "k_final"]
+
+    def var_name(terms, tag):  # what pick_tm's balanced group size selects (csrc/gs_amd.hip)
+        tm = o["var_tm"]
+        if terms < 2 or tm <= 1:
+            return "k_var" + tag
+        ng = (terms + tm - 1) // tm
+        eff = (terms + ng - 1) // ng
+        return ("k_var" if eff <= 1 else "k_var_multi4" if eff <= 4 else "k_var_multi8") + tag
+
+    if xg:
+        ex.append(var_name(m + n, ".g1"))
+    if yg:
+        ex.append(var_name(m + n, ".g2"))
+    ex.append(var_name(m, ".vg1"))
+    return ex
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+@pytest.mark.parametrize("ty", [0, 1, 2, 3])
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])
+def test_forced_kernel_shapes_match_oracle(cname, cid, ty, shape):
+    o = SHAPES[shape]
+    N, m, n = 66, 4, 4  # two waves per task, the second one ragged
+    run_batch(cid, cname, ty, N, m, n, range(N), opts=o, expect=expected_kernels(ty, m, n, o), seed=9100 + ty)
+
+
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])
+def test_forced_shapes_wide_statement(cname, cid):
+    """8 x 3 PPE: 8-term Straus groups on the verifier's G1 side too (k_var_multi8.vg1), 11 pairs in the b = 1 cells
+    (two twin lanes of 6 + 5), uneven Miller lanes."""
+    o = SHAPES["twin6_straus8_lane"]
+    run_batch(cid, cname, 0, 40, 8, 3, range(40), opts=o, expect=expected_kernels(0, 8, 3, o) + ["k_var_multi8.vg1"],
+              seed=9200)

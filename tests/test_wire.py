@@ -108,6 +108,19 @@ def test_device_decoder_rejects_what_the_oracle_rejects(twin, cname):  # noqa: F
         else:
             bad[-1] |= 0x40
         assert both(bad, group, True) == 0
+        # the identity: exactly one encoding (flag + all-zero payload); the sort flag together with the infinity flag is
+        # malformed (ark-bls12-381 EncodingFlags), and so is a non-zero payload under the infinity flag
+        ident = bytearray(W.enc_point(None, group, True))
+        assert both(ident, group, True) == 1
+        bad = bytearray(ident)
+        if zc:
+            bad[0] |= 0x20
+        else:
+            bad[-1] |= 0x80
+        assert both(bad, group, True) == 0
+        bad = bytearray(ident)
+        bad[len(bad) // 2] ^= 1
+        assert both(bad, group, True) == 0
         # non-canonical x (= p): rejected before any arithmetic
         n = c.nq * 8
         pbytes = c.p.to_bytes(n, "big" if zc else "little")
