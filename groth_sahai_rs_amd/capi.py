@@ -25,6 +25,9 @@ SYMBOLS = [
     "gs_wire_sizes", "gs_wire_encode_g1", "gs_wire_encode_g2", "gs_wire_decode_g1", "gs_wire_decode_g2",
     "gs_wire_encode_fr", "gs_wire_decode_fr", "gs_wire_encode_gt", "gs_wire_decode_gt",
     "gs_prof_enable", "gs_prof_reset", "gs_prof_get", "gs_prof_get_work",
+    "gs_ctx_create_multi", "gs_multi_destroy", "gs_multi_ndev", "gs_multi_ctx", "gs_multi_last_error",
+    "gs_multi_uses_rccl", "gs_multi_shard", "gs_multi_set_crs", "gs_multi_prove_batch", "gs_multi_verify_batch",
+    "gs_multi_verify_batch_rlc",
 ]
 
 
@@ -398,3 +401,98 @@ class Engine:
             self._chk(self.lib.gs_prof_get_work(self.ctx, i, ctypes.byref(lanes), ctypes.byref(work)))
             out[name] = (lanes.value, work.value)
         return out
+
+
+class MultiEngine:
+    """gs_ctx_create_multi: the devices of one node behind one handle.  Host arrays in, host arrays out; the batch is
+    cut into contiguous equation blocks, one per device (include/gs_amd.h, multi-GPU section)."""
+
+    def __init__(self, curve=CURVE_BLS12_381, devices=(0,)):
+        self.lib = load_library()
+        self.lib.gs_multi_last_error.restype = ctypes.c_char_p
+        self.lib.gs_multi_ctx.restype = ctypes.c_void_p
+        self.curve = curve
+        self.devices = list(devices)
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        self.h = ctypes.c_void_p()
+        rc = self.lib.gs_ctx_create_multi(curve, arr, len(self.devices), ctypes.byref(self.h))
+        if rc != 0:
+            raise GsError(rc, "gs_ctx_create_multi failed (no usable HIP device? there is no CPU fallback)")
+        sz = (ctypes.c_size_t * 6)()
+        self.lib.gs_sizes(curve, sz)
+        self.FQ, self.FR, self.G1, self.G2, self.GT, self.CRS = [int(x) for x in sz]
+        self.COM1, self.COM2 = 2 * self.G1, 2 * self.G2
+
+    shape = Engine.shape
+    _check_prove = Engine._check_prove
+    _check_verify = Engine._check_verify
+
+    def close(self):
+        if self.h:
+            self.lib.gs_multi_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GsError(rc, (self.lib.gs_multi_last_error(self.h) or b"").decode())
+
+    def set_option(self, key, value):
+        for i in range(len(self.devices)):
+            ctx = ctypes.c_void_p(self.lib.gs_multi_ctx(self.h, i))
+            if self.lib.gs_set_option(ctx, key.encode(), int(value)) != 0:
+                raise GsError(3, "gs_set_option(%s)" % key)
+
+    def shard(self, N, i):
+        lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+        self._chk(self.lib.gs_multi_shard(self.h, ctypes.c_size_t(N), i, ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    def uses_rccl(self):
+        return bool(self.lib.gs_multi_uses_rccl(self.h))
+
+    def set_crs(self, crs):
+        crs = np.ascontiguousarray(crs).view(np.uint8).reshape(-1)
+        assert crs.size == self.CRS
+        self._chk(self.lib.gs_multi_set_crs(self.h, _p(crs)))
+
+    def prove_batch(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, want_coms=True):
+        sh = self.shape(ty)
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        X, Y, A, B, Gamma, R, S, T = map(u8, (X, Y, A, B, Gamma, R, S, T))
+        self._check_prove("gs_multi_prove_batch", ty, N, m, n, X, Y, A, B, Gamma, R, S, T)
+        z = lambda k: np.zeros(k, dtype=np.uint8)
+        xc = z(N * m * self.COM1) if want_coms else None
+        yc = z(N * n * self.COM2) if want_coms else None
+        pi, th = z(N * sh["kx"] * self.COM2), z(N * sh["ky"] * self.COM1)
+        self._chk(self.lib.gs_multi_prove_batch(self.h, ty, ctypes.c_size_t(N), m, n, _p(X), _p(Y), _p(A), _p(B),
+                                                _p(Gamma), _p(R), _p(S), _p(T), _p(xc), _p(yc), _p(pi), _p(th)))
+        return dict(xcoms=xc, ycoms=yc, pi=pi, theta=th)
+
+    def verify_batch(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta):
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        A, B, Gamma, target, xcoms, ycoms, pi, theta = map(u8, (A, B, Gamma, target, xcoms, ycoms, pi, theta))
+        self._check_verify("gs_multi_verify_batch", ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta)
+        ok = np.zeros(N, dtype=np.uint8)
+        self._chk(self.lib.gs_multi_verify_batch(self.h, ty, ctypes.c_size_t(N), m, n, _p(A), _p(B), _p(Gamma),
+                                                 _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(ok)))
+        return ok
+
+    def verify_batch_rlc(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, rho):
+        """-> (ok_all, the ndev gathered accumulator pairs as bytes)"""
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        A, B, Gamma, target, xcoms, ycoms, pi, theta = map(u8, (A, B, Gamma, target, xcoms, ycoms, pi, theta))
+        self._check_verify("gs_multi_verify_batch_rlc", ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta)
+        rho = np.ascontiguousarray(rho, dtype=np.uint64).reshape(-1)
+        _need("gs_multi_verify_batch_rlc", [("rho", rho, 32 * N)])
+        acc = np.zeros(len(self.devices) * 2 * self.GT, dtype=np.uint8)
+        ok = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.gs_multi_verify_batch_rlc(self.h, ty, ctypes.c_size_t(N), m, n, _p(A), _p(B), _p(Gamma),
+                                                     _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(rho),
+                                                     _p(acc), _p(ok)))
+        return int(ok[0]), acc

@@ -157,6 +157,35 @@ int gs_verify_batch_rlc(gs_ctx*, int equ_type, size_t N, int m, int n, const voi
 /* product of `count` GT accumulators (host), final exponentiation, == 1 ? */
 int gs_gt_finalize(gs_ctx*, size_t count, const void* accs_gt_host, uint8_t* ok_all);
 
+/* ---- several GPUs of one node ----------------------------------------------------------
+ * gs_ctx_create_multi owns one context (stream, scratch, CRS tables) per listed device ordinal.  A batch is cut into
+ * contiguous blocks of equation indices, block i on devices[i] (sizes differ by at most one: gs_multi_shard); every
+ * block runs the single-device entry point of the same name on its own host thread.  Host pointers, whole batch in,
+ * whole batch out, identical bytes to a single-device run.  Prove and exact verify use no collective.  The batched
+ * verifier all-gathers the per-device accumulator pairs (2 GT each) over RCCL, multiplies them in device order and runs
+ * ONE final exponentiation: the verdict for the union of the blocks (same rho contract as gs_verify_batch_rlc; rho is
+ * indexed by GLOBAL equation number).  acc_pairs (may be NULL) receives the ndev gathered pairs.  RCCL is bound at run
+ * time (dlopen of librccl.so, preferring a copy already in the process); only gs_multi_verify_batch_rlc needs it. */
+typedef struct gs_multi gs_multi;
+int gs_ctx_create_multi(int curve_id, const int* device_ordinals, int ndev, gs_multi** out);
+void gs_multi_destroy(gs_multi*);
+int gs_multi_ndev(gs_multi*);
+gs_ctx* gs_multi_ctx(gs_multi*, int i);                      /* devices[i]'s context, e.g. for gs_set_option */
+const char* gs_multi_last_error(gs_multi*);
+int gs_multi_uses_rccl(gs_multi*);                           /* 1 once the RCCL communicators exist */
+int gs_multi_shard(gs_multi*, size_t N, int i, size_t* lo, size_t* hi); /* block [lo, hi) of devices[i] */
+int gs_multi_set_crs(gs_multi*, const void* crs_host);
+int gs_multi_prove_batch(gs_multi*, int equ_type, size_t N, int m, int n, const void* X, const void* Y, const void* A,
+                         const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
+                         void* ycoms, void* pi, void* theta);
+int gs_multi_verify_batch(gs_multi*, int equ_type, size_t N, int m, int n, const void* A, const void* B,
+                          const void* Gamma, const void* target, const void* xcoms, const void* ycoms, const void* pi,
+                          const void* theta, uint8_t* ok);
+int gs_multi_verify_batch_rlc(gs_multi*, int equ_type, size_t N, int m, int n, const void* A, const void* B,
+                              const void* Gamma, const void* target, const void* xcoms, const void* ycoms,
+                              const void* pi, const void* theta, const uint64_t* rho, void* acc_pairs_gt,
+                              uint8_t* ok_all);
+
 /* ---- L2 parity hooks (host pointers) ------------------------------------- */
 /* out[i] = sum_k lhs[i][k] * col[k]       (data_structures.rs:696-742) */
 int gs_mat_left_mul_com1(gs_ctx*, int rows, int k, const void* lhs_fr, const void* col_com1, void* out_com1);
