@@ -605,4 +605,71 @@ inline CRS deserialize_crs(const Bytes& b, bool compressed, int curve = GS_CURVE
   return CRS(r.coms<Com1>(u), r.coms<Com2>(v), G1Affine{r.get(g1)}, G2Affine{r.get(g2)}, GT{r.get(gt)}, curve, device);
 }
 
+// ---- several GPUs of one node (gs_ctx_create_multi): a batch of N same-shaped equations, proved / verified in
+// contiguous blocks, one per device.  The reference has no batch type (Statement = Vec<dyn Equ> is unused there), so
+// the batch is given as vectors of equations and per-equation witnesses; everything else follows Equation<>.
+struct MultiCtx {
+  gs_multi* h = nullptr;
+  size_t sz[6] = {0, 0, 0, 0, 0, 0};
+  MultiCtx(int curve, const std::vector<int>& devices) {
+    if (gs_sizes(curve, sz) != GS_OK) throw std::runtime_error("bad curve id");
+    if (gs_ctx_create_multi(curve, devices.data(), (int)devices.size(), &h) != GS_OK)
+      throw std::runtime_error("gs_ctx_create_multi failed (no usable GPU; there is no CPU fallback)");
+  }
+  ~MultiCtx() { gs_multi_destroy(h); }
+  MultiCtx(const MultiCtx&) = delete;
+  MultiCtx& operator=(const MultiCtx&) = delete;
+  void chk(int rc) const {
+    if (rc == GS_ERR_SHAPE) throw Panic(gs_multi_last_error(h));
+    if (rc != GS_OK) throw std::runtime_error(std::string("gs_amd error: ") + gs_multi_last_error(h));
+  }
+  void set_crs(const CRS& crs) {
+    Bytes flat = cat(crs.u), t = cat(crs.v);
+    flat.insert(flat.end(), t.begin(), t.end());
+    flat.insert(flat.end(), crs.g1_gen.v.begin(), crs.g1_gen.v.end());
+    flat.insert(flat.end(), crs.g2_gen.v.begin(), crs.g2_gen.v.end());
+    flat.insert(flat.end(), crs.gt_gen.v.begin(), crs.gt_gen.v.end());
+    assert_eq(flat.size(), sz[5], "CRS size");
+    chk(gs_multi_set_crs(h, flat.data()));
+  }
+  // verify N proofs of N equations of ONE type and shape (m x n); ok[i] as Verifiable::verify of equation i
+  template <class Equ> std::vector<bool> verify_batch(const std::vector<Equ>& equs, const std::vector<CProof>& proofs) {
+    assert_eq(equs.size(), proofs.size(), "equs.len() == proofs.len()");
+    size_t N = equs.size();
+    if (N == 0) return {};
+    size_t m = proofs[0].xcoms.coms.size(), n = proofs[0].ycoms.coms.size();
+    if (m == 0 || n == 0) throw Panic("index out of bounds: empty commitment list");
+    Bytes A, B, G, tg, xc, yc, pi, th;
+    auto app = [](Bytes& d, const Bytes& s) { d.insert(d.end(), s.begin(), s.end()); };
+    for (size_t i = 0; i < N; i++) {
+      const Equ& e = equs[i];
+      const CProof& p = proofs[i];
+      assert_eq(p.equ_proofs.size(), 1, "com_proof.equ_proofs.len() == 1");
+      assert_eq(p.xcoms.coms.size(), m, "same m for the whole batch");
+      assert_eq(p.ycoms.coms.size(), n, "same n for the whole batch");
+      e.check_statement_shape(m, n);
+      assert_eq(p.equ_proofs[0].pi.size(), Equ::KX, "pi.len()");
+      assert_eq(p.equ_proofs[0].theta.size(), Equ::KY, "theta.len()");
+      app(A, cat(e.a_consts));
+      app(B, cat(e.b_consts));
+      app(G, cat(e.gamma));
+      app(tg, e.target.v);
+      app(xc, cat(p.xcoms.coms));
+      app(yc, cat(p.ycoms.coms));
+      app(pi, cat(p.equ_proofs[0].pi));
+      app(th, cat(p.equ_proofs[0].theta));
+    }
+    assert_eq(G.size(), N * m * n * sz[1], "gamma bytes");
+    assert_eq(xc.size(), N * m * 2 * sz[2], "xcoms bytes");
+    assert_eq(yc.size(), N * n * 2 * sz[3], "ycoms bytes");
+    assert_eq(pi.size(), N * Equ::KX * 2 * sz[3], "pi bytes");
+    assert_eq(th.size(), N * Equ::KY * 2 * sz[2], "theta bytes");
+    assert_eq(tg.size() % N, 0, "target bytes");
+    std::vector<uint8_t> ok(N, 0);
+    chk(gs_multi_verify_batch(h, (int)equs[0].get_type(), N, (int)m, (int)n, A.data(), B.data(), G.data(), tg.data(),
+                              xc.data(), yc.data(), pi.data(), th.data(), ok.data()));
+    return std::vector<bool>(ok.begin(), ok.end());
+  }
+};
+
 }  // namespace gs_amd

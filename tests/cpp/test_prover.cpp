@@ -165,6 +165,27 @@ static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const By
     CHECK(!other.verify(proof, crs));
   }
 
+  // the several-GPU entry (gs_ctx_create_multi; one device on this box): a batch of three proofs of the same
+  // statement, the middle one tampered -- verdicts per equation as Verifiable::verify gives them
+  {
+    MultiCtx mc(curve, {0});
+    mc.set_crs(crs);
+    CProof bad = proof;
+    Equ other = equ;
+    other.gamma[0][0] = gflat[0].v == Bytes(fr, 0) ? rng_of({&R}).fr() : Fr{Bytes(fr, 0)};
+    std::vector<bool> ok = mc.verify_batch(std::vector<Equ>{equ, other, equ}, std::vector<CProof>{proof, proof, proof});
+    CHECK(ok.size() == 3 && ok[0] && !ok[1] && ok[2]);
+    bool threw = false;
+    try {
+      CProof shortp = proof;
+      shortp.equ_proofs[0].pi.pop_back();
+      mc.verify_batch(std::vector<Equ>{equ, equ}, std::vector<CProof>{proof, shortp});
+    } catch (const Panic&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
   // shape asserts panic (prove.rs:106-113; verifier.rs:25-26)
   {
     bool threw = false;
