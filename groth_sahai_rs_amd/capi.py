@@ -19,6 +19,7 @@ SYMBOLS = [
     "gs_commit_g1", "gs_commit_g2", "gs_commit_fr_b1", "gs_commit_fr_b2",
     "gs_prove_batch_dev", "gs_prove_batch", "gs_verify_batch_dev", "gs_verify_batch",
     "gs_verify_batch_rlc_dev", "gs_verify_batch_rlc", "gs_gt_finalize",
+    "gs_prove_statement_dev", "gs_prove_statement", "gs_verify_statement_dev", "gs_verify_statement",
     "gs_mat_left_mul_com1", "gs_mat_left_mul_com2", "gs_pairing_sum", "gs_fr_matmul",
     "gs_g1_mul_batch", "gs_g2_mul_batch", "gs_g1_mul_batch_dev", "gs_g2_mul_batch_dev",
     "gs_multi_pairing_batch", "gs_multi_pairing_batch_dev", "gs_gt_pow_batch_dev",
@@ -223,6 +224,41 @@ class Engine:
         self._chk(self.lib.gs_verify_batch(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(A)), _p(u8(B)),
                                            _p(u8(Gamma)), _p(u8(target)), _p(u8(xcoms)), _p(u8(ycoms)), _p(u8(pi)),
                                            _p(u8(theta)), _p(ok)))
+        return ok
+
+    def prove_statement(self, ty, E, m, n, X, Y, A, B, Gamma, R, S, T, want_coms=True):
+        """E equations of one type over the SAME variables X[m], Y[n] (commit randomness R, S): commitments once,
+        one proof per equation (gs_prove_statement)."""
+        sh = self.shape(ty)
+        kx, ky, sx, sy = sh["kx"], sh["ky"], sh["sx"], sh["sy"]
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        X, Y, A, B, Gamma, R, S, T = map(u8, (X, Y, A, B, Gamma, R, S, T))
+        if not (0 <= ty <= 3) or m < 1 or n < 1:
+            raise GsError(1, "gs_prove_statement: bad equation type or empty variable list")
+        _need("gs_prove_statement", [("X", X, m * sx), ("Y", Y, n * sy), ("A", A, E * n * sx), ("B", B, E * m * sy),
+                                     ("Gamma", Gamma, E * m * n * self.FR), ("R", R, m * kx * self.FR),
+                                     ("S", S, n * ky * self.FR), ("T", T, E * ky * kx * self.FR)])
+        xc = self._out(m * self.COM1) if want_coms else None
+        yc = self._out(n * self.COM2) if want_coms else None
+        pi, th = self._out(E * kx * self.COM2), self._out(E * ky * self.COM1)
+        self._chk(self.lib.gs_prove_statement(self.ctx, ty, ctypes.c_size_t(E), m, n, _p(X), _p(Y), _p(A), _p(B),
+                                              _p(Gamma), _p(R), _p(S), _p(T), _p(xc), _p(yc), _p(pi), _p(th)))
+        return dict(xcoms=xc, ycoms=yc, pi=pi, theta=th)
+
+    def verify_statement(self, ty, E, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta):
+        sh = self.shape(ty)
+        kx, ky, sx, sy, st = sh["kx"], sh["ky"], sh["sx"], sh["sy"], sh["st"]
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        A, B, Gamma, target, xcoms, ycoms, pi, theta = map(u8, (A, B, Gamma, target, xcoms, ycoms, pi, theta))
+        if not (0 <= ty <= 3) or m < 1 or n < 1:
+            raise GsError(1, "gs_verify_statement: bad equation type or empty variable list")
+        _need("gs_verify_statement", [("A", A, E * n * sx), ("B", B, E * m * sy), ("Gamma", Gamma, E * m * n * self.FR),
+                                      ("target", target, E * st), ("xcoms", xcoms, m * self.COM1),
+                                      ("ycoms", ycoms, n * self.COM2), ("pi", pi, E * kx * self.COM2),
+                                      ("theta", theta, E * ky * self.COM1)])
+        ok = np.zeros(E, dtype=np.uint8)
+        self._chk(self.lib.gs_verify_statement(self.ctx, ty, ctypes.c_size_t(E), m, n, _p(A), _p(B), _p(Gamma),
+                                               _p(target), _p(xcoms), _p(ycoms), _p(pi), _p(theta), _p(ok)))
         return ok
 
     def verify_batch_rlc(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, rho):

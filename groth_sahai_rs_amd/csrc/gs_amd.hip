@@ -639,9 +639,11 @@ template <class C> struct Impl {
   }
 
   // prove / commit_and_prove for all four types (prove.rs:71-489)
+  // shared: a Statement -- the N equations are over the SAME variables X, Y and commit randomness R, S (one copy,
+  // stride 0); constants, Gamma, T and the proofs stay per equation.  Commitments are then made once by the caller.
   static int prove(gs_ctx* c, int ty, size_t N, int m, int n, const void* X, const void* Y, const void* A,
                    const void* B, const void* G, const void* R, const void* Sm, const void* T, void* xcoms,
-                   void* ycoms, void* pi, void* theta) {
+                   void* ycoms, void* pi, void* theta, bool shared = false) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
     int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     PoolMap pm = prove_pool(m, n, kx, ky);
@@ -651,15 +653,15 @@ template <class C> struct Impl {
       int W = m * kx + n * ky + ky * kx + m + n + kx * n + ky * m;
       RC(launch(c, "k_prep_prove.a", k_prep_prove_wide_a<C>, N * (size_t)W, 64, N * (size_t)W, W, m, n, kx, ky,
                 (const S*)G, (const S*)R, (const S*)Sm, (const S*)T, xg ? nullptr : (const S*)X,
-                yg ? nullptr : (const S*)Y, pm, (S*)pool));
+                yg ? nullptr : (const S*)Y, pm, (S*)pool, shared ? 1 : 0));
       size_t tb = N * (size_t)(kx * ky + kx + ky);
       RC(launch(c, "k_prep_prove.b", k_prep_prove_wide_b<C>, tb, 64, tb, m, n, kx, ky, (const S*)R, (const S*)Sm,
                 (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
-                yg ? nullptr : (const S*)B, pm, (S*)pool));
+                yg ? nullptr : (const S*)B, pm, (S*)pool, shared ? 1 : 0));
     } else {
       RC(launch(c, "k_prep_prove", k_prep_prove<C>, N, 64, N, m, n, kx, ky, (const S*)G, (const S*)R, (const S*)Sm,
                 (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
-                yg ? nullptr : (const S*)B, pm, (S*)pool));
+                yg ? nullptr : (const S*)B, pm, (S*)pool, shared ? 1 : 0));
     }
     // small batches: G1 side on the context's stream, G2 side on side[0], each side's variable-base kernel on a
     // further stream; everything joins back before this function returns
@@ -687,7 +689,7 @@ template <class C> struct Impl {
       memset(&arrs, 0, sizeof arrs);
       if (xg) {
         arrs.base[0] = (const uint8_t*)X;
-        arrs.stride[0] = (uint32_t)(m * Z::G1);
+        arrs.stride[0] = shared ? 0u : (uint32_t)(m * Z::G1);
         arrs.base[1] = (const uint8_t*)A;
         arrs.stride[1] = (uint32_t)(n * Z::G1);
       }
@@ -709,7 +711,7 @@ template <class C> struct Impl {
       memset(&arrs, 0, sizeof arrs);
       if (yg) {
         arrs.base[0] = (const uint8_t*)Y;
-        arrs.stride[0] = (uint32_t)(n * Z::G2);
+        arrs.stride[0] = shared ? 0u : (uint32_t)(n * Z::G2);
         arrs.base[1] = (const uint8_t*)B;
         arrs.stride[1] = (uint32_t)(m * Z::G2);
       }
@@ -757,7 +759,7 @@ template <class C> struct Impl {
     // reuse k_prep_prove with m = 1 variable per "equation", no Gamma work (n = 0, ky = 0)
     RC(launch(c, "k_prep_commit", k_prep_prove<C>, count, 64, count, 1, 0, kc, 0, (const S*)nullptr, (const S*)rand,
               (const S*)nullptr, (const S*)nullptr, group ? nullptr : (const S*)vars, (const S*)nullptr,
-              (const S*)nullptr, (const S*)nullptr, pm, (S*)pool));
+              (const S*)nullptr, (const S*)nullptr, pm, (S*)pool, 0));
     SidePlan sp;
     build_side(sp, true, 1, 0, group, kc, 0, pm.RC, pm.XC, 0, 0, 0, 0);
     ArrTab arrs;
@@ -877,7 +879,7 @@ template <class C> struct Impl {
   // shared front of both verifier modes: G1-side points + Miller partials
   static int verify_front(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
                           const void* target, const void* xcoms, const void* ycoms, const void* pi,
-                          const void* theta, VerifyPlan& vp, void** mpart_out) {
+                          const void* theta, VerifyPlan& vp, void** mpart_out, bool shared = false) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
     int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     PoolMap pm;
@@ -924,7 +926,7 @@ template <class C> struct Impl {
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
       arrs.base[0] = (const uint8_t*)xcoms;
-      arrs.stride[0] = (uint32_t)(m * Z::COM1);
+      arrs.stride[0] = shared ? 0u : (uint32_t)(m * Z::COM1);  // a Statement's equations share the commitments
       if (xg) {
         arrs.base[1] = (const uint8_t*)A;
         arrs.stride[1] = (uint32_t)(n * Z::G1);
@@ -951,13 +953,13 @@ template <class C> struct Impl {
     parr.base[0] = (const uint8_t*)pa;
     parr.stride[0] = (uint32_t)(vp.npa * Z::COM1);
     parr.base[1] = (const uint8_t*)xcoms;
-    parr.stride[1] = (uint32_t)(m * Z::COM1);
+    parr.stride[1] = shared ? 0u : (uint32_t)(m * Z::COM1);
     parr.base[2] = (const uint8_t*)c->tabs->crs_g1.p;
     parr.stride[2] = 0;
     parr.base[3] = (const uint8_t*)theta;
     parr.stride[3] = (uint32_t)(ky * Z::COM1);
     qarr.base[0] = (const uint8_t*)ycoms;
-    qarr.stride[0] = (uint32_t)(n * Z::COM2);
+    qarr.stride[0] = shared ? 0u : (uint32_t)(n * Z::COM2);
     qarr.base[1] = (const uint8_t*)B;
     qarr.stride[1] = (uint32_t)(m * Z::G2);
     qarr.base[2] = (const uint8_t*)c->tabs->crs_g2.p;
@@ -986,10 +988,10 @@ template <class C> struct Impl {
 
   static int verify(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
                     const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
-                    uint8_t* ok) {
+                    uint8_t* ok, bool shared = false) {
     VerifyPlan vp;
     void* mpart;
-    RC(verify_front(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, vp, &mpart));
+    RC(verify_front(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, vp, &mpart, shared));
     int ntask = (int)vp.mt.size();
     void* cellok;
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
@@ -1359,11 +1361,11 @@ template <class C> static int fr_matmul_impl(gs_ctx* c, int rows, int inner, int
   if (wide_prep(m, n)) {
     int W = m * kx + n * ky + ky * kx + m + n + kx * n + ky * m;
     RC(launch(c, "k_prep_prove.a", k_prep_prove_wide_a<C>, (size_t)W, 64, (size_t)W, W, m, n, kx, ky, (const S*)dG,
-              (const S*)dR, (const S*)dR, (const S*)dR, (const S*)nullptr, (const S*)nullptr, pm, (S*)pool));
+              (const S*)dR, (const S*)dR, (const S*)dR, (const S*)nullptr, (const S*)nullptr, pm, (S*)pool, 0));
   } else {
     RC(launch(c, "k_prep_prove", k_prep_prove<C>, 1, 64, (size_t)1, m, n, kx, ky, (const S*)dG, (const S*)dR,
               (const S*)dR, (const S*)dR, (const S*)nullptr, (const S*)nullptr, (const S*)nullptr, (const S*)nullptr, pm,
-              (S*)pool));
+              (S*)pool, 0));
   }
   size_t cnt = (size_t)rows * cols;
   RC(launch(c, "k_fr_to_mont", k_fr_to_mont<C>, cnt, 64, cnt, (const S*)pool + pm.PSI, (S*)dout));
@@ -1737,6 +1739,85 @@ int gs_verify_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, co
   RC(st.out(ok, N, &dok));
   RC(gs_verify_batch_dev(c, ty, N, m, n, dA, dB, dG, dt, dxc, dyc, dpi, dth, (uint8_t*)dok));
   return st.back(ok, dok, N);
+}
+
+// ---- Statement: E equations of one type over the SAME committed variables (statement.rs:24-28,109) -------------
+int gs_prove_statement_dev(gs_ctx* c, int ty, size_t E, int m, int n, const void* X, const void* Y, const void* A,
+                           const void* B, const void* G, const void* R, const void* S, const void* T, void* xcoms,
+                           void* ycoms, void* pi, void* theta) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (E == 0) return GS_OK;
+  if (!X || !Y || !A || !B || !G || !R || !S || !T || !pi || !theta) return fail(c, GS_ERR_ARG, "null pointer");
+  bool xg = x_is_group(ty), yg = y_is_group(ty);
+  // the commitments, once (commit.rs:78-100,125-156,178-200,225-256)
+  if (xcoms) RC((xg ? gs_commit_g1_dev : gs_commit_fr_b1_dev)(c, (size_t)m, X, R, xcoms));
+  if (ycoms) RC((yg ? gs_commit_g2_dev : gs_commit_fr_b2_dev)(c, (size_t)n, Y, S, ycoms));
+  return DISPATCH(c, prove(c, ty, E, m, n, X, Y, A, B, G, R, S, T, nullptr, nullptr, pi, theta, true));
+}
+int gs_verify_statement_dev(gs_ctx* c, int ty, size_t E, int m, int n, const void* A, const void* B, const void* G,
+                            const void* target, const void* xcoms, const void* ycoms, const void* pi,
+                            const void* theta, uint8_t* ok) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (E == 0) return GS_OK;
+  if (!A || !B || !G || !target || !xcoms || !ycoms || !pi || !theta || !ok) return fail(c, GS_ERR_ARG, "null pointer");
+  return DISPATCH(c, verify(c, ty, E, m, n, A, B, G, target, xcoms, ycoms, pi, theta, ok, true));
+}
+int gs_prove_statement(gs_ctx* c, int ty, size_t E, int m, int n, const void* X, const void* Y, const void* A,
+                       const void* B, const void* G, const void* R, const void* S, const void* T, void* xcoms,
+                       void* ycoms, void* pi, void* theta) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (E == 0) return GS_OK;
+  size_t fq = sz_fq(c->curve);
+  bool xg = x_is_group(ty), yg = y_is_group(ty);
+  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
+  HostStage st(c);
+  void *dX, *dY, *dA, *dB, *dG, *dR, *dS, *dT, *dxc, *dyc, *dpi, *dth;
+  RC(st.in(X, (size_t)m * sx, &dX));
+  RC(st.in(Y, (size_t)n * sy, &dY));
+  RC(st.in(A, E * n * sx, &dA));
+  RC(st.in(B, E * m * sy, &dB));
+  RC(st.in(G, E * m * n * SZ_FR, &dG));
+  RC(st.in(R, (size_t)m * kx * SZ_FR, &dR));
+  RC(st.in(S, (size_t)n * ky * SZ_FR, &dS));
+  RC(st.in(T, E * ky * kx * SZ_FR, &dT));
+  RC(st.out(xcoms, (size_t)m * 4 * fq, &dxc));
+  RC(st.out(ycoms, (size_t)n * 8 * fq, &dyc));
+  RC(st.out(pi, E * kx * 8 * fq, &dpi));
+  RC(st.out(theta, E * ky * 4 * fq, &dth));
+  RC(gs_prove_statement_dev(c, ty, E, m, n, dX, dY, dA, dB, dG, dR, dS, dT, dxc, dyc, dpi, dth));
+  RC(st.back(xcoms, dxc, (size_t)m * 4 * fq));
+  RC(st.back(ycoms, dyc, (size_t)n * 8 * fq));
+  RC(st.back(pi, dpi, E * kx * 8 * fq));
+  return st.back(theta, dth, E * ky * 4 * fq);
+}
+int gs_verify_statement(gs_ctx* c, int ty, size_t E, int m, int n, const void* A, const void* B, const void* G,
+                        const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                        uint8_t* ok) {
+  RC(check_ctx(c, true));
+  RC(check_shape(c, ty, m, n));
+  if (E == 0) return GS_OK;
+  size_t fq = sz_fq(c->curve);
+  bool xg = x_is_group(ty), yg = y_is_group(ty);
+  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
+  size_t st_ = ty == GS_PPE ? 12 * fq : ty == GS_MSMEG1 ? 2 * fq : ty == GS_MSMEG2 ? 4 * fq : SZ_FR;
+  HostStage st(c);
+  void *dA, *dB, *dG, *dt, *dxc, *dyc, *dpi, *dth, *dok;
+  RC(st.in(A, E * n * sx, &dA));
+  RC(st.in(B, E * m * sy, &dB));
+  RC(st.in(G, E * m * n * SZ_FR, &dG));
+  RC(st.in(target, E * st_, &dt));
+  RC(st.in(xcoms, (size_t)m * 4 * fq, &dxc));
+  RC(st.in(ycoms, (size_t)n * 8 * fq, &dyc));
+  RC(st.in(pi, E * kx * 8 * fq, &dpi));
+  RC(st.in(theta, E * ky * 4 * fq, &dth));
+  RC(st.out(ok, E, &dok));
+  RC(gs_verify_statement_dev(c, ty, E, m, n, dA, dB, dG, dt, dxc, dyc, dpi, dth, (uint8_t*)dok));
+  return st.back(ok, dok, E);
 }
 
 // ---- helpers / hooks -----------------------------------------------------------

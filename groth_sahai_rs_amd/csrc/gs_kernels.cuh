@@ -198,22 +198,28 @@ template <class C>
 __global__ void __launch_bounds__(64, GS_WPE)
     k_prep_prove(size_t N, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R, const Fr<C>* S,
                  const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm,
-                 Fr<C>* pool) {
+                 Fr<C>* pool, int shared_vars) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   typedef Fr<C> S_;
+  // shared_vars: a Statement -- every equation of the batch is over the SAME variables (and commit randomness)
+  const size_t ev = shared_vars ? 0 : e;
   G += e * m * n;
-  R += e * m * kx;
-  S += e * n * ky;
+  R += ev * m * kx;
+  S += ev * n * ky;
   T += e * ky * kx;
+  if (xs) xs += ev * m;
+  if (ys) ys += ev * n;
+  if (as) as += e * n;
+  if (bs) bs += e * m;
   S_* P = pool + e * pm.total;
   for (int i = 0; i < m * kx; i++) P[pm.RC + i] = from_mont(R[i]);
   for (int i = 0; i < n * ky; i++) P[pm.SC + i] = from_mont(S[i]);
   for (int i = 0; i < ky * kx; i++) P[pm.TC + i] = from_mont(T[i]);
   if (xs)
-    for (int i = 0; i < m; i++) P[pm.XC + i] = from_mont(xs[e * m + i]);
+    for (int i = 0; i < m; i++) P[pm.XC + i] = from_mont(xs[i]);
   if (ys)
-    for (int j = 0; j < n; j++) P[pm.YC + j] = from_mont(ys[e * n + j]);
+    for (int j = 0; j < n; j++) P[pm.YC + j] = from_mont(ys[j]);
   // Psi = R^T Gamma (kx x n); Omega = Psi S - T^T (kx x ky); rho_k (scalar-Y types)
   for (int k = 0; k < kx; k++) {
     S_ om[2] = {fzero<FrM<C>>(), fzero<FrM<C>>()};
@@ -223,11 +229,11 @@ __global__ void __launch_bounds__(64, GS_WPE)
       for (int i = 0; i < m; i++) psi = add(psi, mul(R[i * kx + k], G[i * n + j]));
       P[pm.PSI + k * n + j] = from_mont(psi);
       for (int l = 0; l < ky; l++) om[l] = add(om[l], mul(psi, S[j * ky + l]));
-      if (ys) rho = add(rho, mul(psi, ys[e * n + j]));
+      if (ys) rho = add(rho, mul(psi, ys[j]));
     }
     for (int l = 0; l < ky; l++) P[pm.OM + k * ky + l] = from_mont(sub(om[l], T[l * kx + k]));
     if (bs) {
-      for (int i = 0; i < m; i++) rho = add(rho, mul(R[i * kx + k], bs[e * m + i]));
+      for (int i = 0; i < m; i++) rho = add(rho, mul(R[i * kx + k], bs[i]));
       P[pm.RHO + k] = from_mont(rho);
     }
   }
@@ -238,10 +244,10 @@ __global__ void __launch_bounds__(64, GS_WPE)
       S_ phi = fzero<FrM<C>>();
       for (int j = 0; j < n; j++) phi = add(phi, mul(S[j * ky + l], G[i * n + j]));
       P[pm.PHI + l * m + i] = from_mont(phi);
-      if (xs) sig = add(sig, mul(phi, xs[e * m + i]));
+      if (xs) sig = add(sig, mul(phi, xs[i]));
     }
     if (as) {
-      for (int j = 0; j < n; j++) sig = add(sig, mul(S[j * ky + l], as[e * n + j]));
+      for (int j = 0; j < n; j++) sig = add(sig, mul(S[j * ky + l], as[j]));
       P[pm.SIG + l] = from_mont(sig);
     }
   }
@@ -253,16 +259,20 @@ __global__ void __launch_bounds__(64, GS_WPE)
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE)
     k_prep_prove_wide_a(size_t total, int W, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R,
-                        const Fr<C>* S, const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, PoolMap pm, Fr<C>* pool) {
+                        const Fr<C>* S, const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, PoolMap pm, Fr<C>* pool,
+                        int shared_vars) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   size_t e = g / W;
   int w = (int)(g % W);
   typedef Fr<C> S_;
+  const size_t ev = shared_vars ? 0 : e;
   G += e * m * n;
-  R += e * m * kx;
-  S += e * n * ky;
+  R += ev * m * kx;
+  S += ev * n * ky;
   T += e * ky * kx;
+  if (xs) xs += ev * m;
+  if (ys) ys += ev * n;
   S_* P = pool + e * pm.total;
   int o = 0;
   if (w < o + m * kx) { P[pm.RC + w - o] = from_mont(R[w - o]); return; }
@@ -271,9 +281,9 @@ __global__ void __launch_bounds__(64, GS_WPE)
   o += n * ky;
   if (w < o + ky * kx) { P[pm.TC + w - o] = from_mont(T[w - o]); return; }
   o += ky * kx;
-  if (w < o + m) { if (xs) P[pm.XC + w - o] = from_mont(xs[e * m + w - o]); return; }
+  if (w < o + m) { if (xs) P[pm.XC + w - o] = from_mont(xs[w - o]); return; }
   o += m;
-  if (w < o + n) { if (ys) P[pm.YC + w - o] = from_mont(ys[e * n + w - o]); return; }
+  if (w < o + n) { if (ys) P[pm.YC + w - o] = from_mont(ys[w - o]); return; }
   o += n;
   if (w < o + kx * n) {  // Psi[k][j] = sum_i R[i][k] G[i][j]
     int k = (w - o) / n, j = (w - o) % n;
@@ -293,16 +303,22 @@ __global__ void __launch_bounds__(64, GS_WPE)
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE)
     k_prep_prove_wide_b(size_t total, int m, int n, int kx, int ky, const Fr<C>* R, const Fr<C>* S, const Fr<C>* T,
-                        const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm, Fr<C>* pool) {
+                        const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm, Fr<C>* pool,
+                        int shared_vars) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   const int W = kx * ky + kx + ky;
   size_t e = g / W;
   int w = (int)(g % W);
   typedef Fr<C> S_;
-  R += e * m * kx;
-  S += e * n * ky;
+  const size_t ev = shared_vars ? 0 : e;
+  R += ev * m * kx;
+  S += ev * n * ky;
   T += e * ky * kx;
+  if (xs) xs += ev * m;
+  if (ys) ys += ev * n;
+  if (as) as += e * n;
+  if (bs) bs += e * m;
   S_* P = pool + e * pm.total;
   if (w < kx * ky) {  // Omega[k][l] = sum_j Psi[k][j] S[j][l] - T[l][k]
     int k = w / ky, l = w % ky;
@@ -314,16 +330,16 @@ __global__ void __launch_bounds__(64, GS_WPE)
     if (!bs) return;
     S_ rho = fzero<FrM<C>>();
     if (ys)
-      for (int j = 0; j < n; j++) rho = add(rho, mul(to_mont(P[pm.PSI + k * n + j]), ys[e * n + j]));
-    for (int i = 0; i < m; i++) rho = add(rho, mul(R[i * kx + k], bs[e * m + i]));
+      for (int j = 0; j < n; j++) rho = add(rho, mul(to_mont(P[pm.PSI + k * n + j]), ys[j]));
+    for (int i = 0; i < m; i++) rho = add(rho, mul(R[i * kx + k], bs[i]));
     P[pm.RHO + k] = from_mont(rho);
   } else {  // sigma_l = sum_i Phi[l][i] x_i + sum_j S[j][l] a_j   (scalar-X types)
     int l = w - kx * ky - kx;
     if (!as) return;
     S_ sig = fzero<FrM<C>>();
     if (xs)
-      for (int i = 0; i < m; i++) sig = add(sig, mul(to_mont(P[pm.PHI + l * m + i]), xs[e * m + i]));
-    for (int j = 0; j < n; j++) sig = add(sig, mul(S[j * ky + l], as[e * n + j]));
+      for (int i = 0; i < m; i++) sig = add(sig, mul(to_mont(P[pm.PHI + l * m + i]), xs[i]));
+    for (int j = 0; j < n; j++) sig = add(sig, mul(S[j * ky + l], as[j]));
     P[pm.SIG + l] = from_mont(sig);
   }
 }

@@ -221,3 +221,59 @@ class MSMEG2(_Equation):
 
 class QuadEqu(_Equation):
     TYPE = GS_QUAD
+
+
+class Statement:
+    """`pub type Statement = Vec<dyn Equ>` (statement.rs:109) made usable: a list of equations of ONE type over the same
+    variables (statement.rs:24-28: "each equation is defined with respect to the list of variables that span across
+    ALL equations").  The variables are committed once; every equation gets its own EquProof against those
+    commitments -- exactly what batch_commit_* followed by `equ.prove(..)` per equation does in the reference, in
+    one call of the engine (gs_prove_statement / gs_verify_statement).  RNG draw order: R, S, then T of equation 0, 1, ..
+    """
+
+    def __init__(self, equations):
+        assert len(equations) >= 1 and all(e.TYPE == equations[0].TYPE for e in equations)
+        self.equations = list(equations)
+        self.TYPE = equations[0].TYPE
+
+    def _kxky(self):
+        return self.equations[0]._kxky()
+
+    def commit_and_prove(self, xvars, yvars, crs, rng):
+        kx, ky = self._kxky()
+        m, n, E = len(xvars), len(yvars), len(self.equations)
+        assert m >= 1 and n >= 1
+        for equ in self.equations:
+            equ._check_statement_shape(m, n)
+        R = [[rng.fr() for _ in range(kx)] for _ in range(m)]
+        S = [[rng.fr() for _ in range(ky)] for _ in range(n)]
+        Ts = [[[rng.fr() for _ in range(kx)] for _ in range(ky)] for _ in range(E)]
+        cat = np.concatenate
+        out = crs.engine.prove_statement(
+            self.TYPE, E, m, n, _cat(xvars, 0), _cat(yvars, 0), cat([_cat(e.a_consts, 0) for e in self.equations]),
+            cat([_cat(e.b_consts, 0) for e in self.equations]), cat([_flat_mat(e.gamma) for e in self.equations]),
+            _flat_mat(R), _flat_mat(S), cat([_flat_mat(T) for T in Ts]))
+        xcoms = Commit1(_split(out["xcoms"], m), R)
+        ycoms = Commit2(_split(out["ycoms"], n), S)
+        pis, ths = _split(out["pi"], E * kx), _split(out["theta"], E * ky)
+        proofs = [EquProof(pis[e * kx:(e + 1) * kx], ths[e * ky:(e + 1) * ky], self.TYPE, Ts[e]) for e in range(E)]
+        return CProof(xcoms, ycoms, proofs)
+
+    def verify(self, com_proof, crs):
+        """[bool per equation]; the statement holds iff all are true"""
+        kx, ky = self._kxky()
+        E = len(self.equations)
+        assert len(com_proof.equ_proofs) == E
+        m, n = len(com_proof.xcoms.coms), len(com_proof.ycoms.coms)
+        assert m >= 1 and n >= 1
+        for equ, pf in zip(self.equations, com_proof.equ_proofs):
+            equ._check_statement_shape(m, n)
+            assert pf.equ_type == self.TYPE and len(pf.pi) == kx and len(pf.theta) == ky
+        cat = np.concatenate
+        ok = crs.engine.verify_statement(
+            self.TYPE, E, m, n, cat([_cat(e.a_consts, 0) for e in self.equations]),
+            cat([_cat(e.b_consts, 0) for e in self.equations]), cat([_flat_mat(e.gamma) for e in self.equations]),
+            cat([np.asarray(e.target, dtype=np.uint64).reshape(-1) for e in self.equations]),
+            _cat(com_proof.xcoms.coms, 0), _cat(com_proof.ycoms.coms, 0),
+            cat([_cat(pf.pi, 0) for pf in com_proof.equ_proofs]), cat([_cat(pf.theta, 0) for pf in com_proof.equ_proofs]))
+        return [bool(v) for v in ok]

@@ -124,6 +124,18 @@ int gs_prove_batch(gs_ctx*, int equ_type, size_t N, int m, int n, const void* X,
                    const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
                    void* ycoms, void* pi, void* theta);
 
+/* A Statement (src/statement.rs:24-28,109: "a list of equations ... defined with respect to the list of variables that
+ * span across ALL equations"): E equations of ONE type over the SAME m + n variables.  The variables are committed ONCE
+ * (X[m], Y[n] with randomness R[m][kx], S[n][ky]: exactly gs_commit_*), every equation e gets its own proof from its
+ * A[e], B[e], Gamma[e] and T[e][ky][kx] -- what calling Provable::prove E times with the same commitments does
+ * (prove.rs:92-171 ...).  xcoms[m] / ycoms[n] may be NULL (already committed).  pi: E*kx Com2, theta: E*ky Com1. */
+int gs_prove_statement_dev(gs_ctx*, int equ_type, size_t E, int m, int n, const void* X, const void* Y, const void* A,
+                           const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
+                           void* ycoms, void* pi, void* theta);
+int gs_prove_statement(gs_ctx*, int equ_type, size_t E, int m, int n, const void* X, const void* Y, const void* A,
+                       const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
+                       void* ycoms, void* pi, void* theta);
+
 /* ---- verify (src/verifier.rs) ------------------------------------------- */
 /* ok[i] = 1 iff equation i verifies; exact reference semantics (four GT cell
  * equalities per equation). */
@@ -133,6 +145,13 @@ int gs_verify_batch_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const voi
 int gs_verify_batch(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A, const void* B, const void* Gamma,
                     const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
                     uint8_t* ok);
+/* ok[e] = 1 iff equation e of a Statement verifies against the SHARED commitments xcoms[m], ycoms[n]. */
+int gs_verify_statement_dev(gs_ctx*, int equ_type, size_t E, int m, int n, const void* A, const void* B,
+                            const void* Gamma, const void* target, const void* xcoms, const void* ycoms,
+                            const void* pi, const void* theta, uint8_t* ok);
+int gs_verify_statement(gs_ctx*, int equ_type, size_t E, int m, int n, const void* A, const void* B, const void* Gamma,
+                        const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
+                        uint8_t* ok);
 /* Batched pairing-product check: random linear combination of all 4N cell
  * equations with caller-supplied 64-bit exponents rho[N][4] (device/host u64).
  * RHO CONTRACT (soundness rests on it): every rho is drawn from a CSPRNG, fresh for every call, NON-ZERO, secret

@@ -85,6 +85,14 @@ class CurveInfo:
             return None
         return ["%x" % self.fq_dec(x) for x in a]
 
+    def com1_dec(self, a):
+        a = np.asarray(a, dtype=np.uint64).reshape(2, 2 * self.nq)
+        return [self.g1_dec(a[0]), self.g1_dec(a[1])]
+
+    def com2_dec(self, a):
+        a = np.asarray(a, dtype=np.uint64).reshape(2, 4 * self.nq)
+        return [self.g2_dec(a[0]), self.g2_dec(a[1])]
+
     def f12_dec(self, a):
         a = np.asarray(a, dtype=np.uint64).reshape(12, self.nq)
         return ["%x" % self.fq_dec(x) for x in a]

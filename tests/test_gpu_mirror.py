@@ -168,6 +168,49 @@ def test_verify_rejects_malformed_lengths(setup):
     assert equ.verify(proof, crs)
 
 
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_statement_with_shared_commitments(setup, idx):
+    """A Statement (statement.rs:24-28,109): three equations of one type over the SAME variables.  Committing once and
+    proving every equation in one engine call must equal batch_commit_* followed by `equ.prove` per equation under a
+    synchronised RNG (draw order R, S, T0, T1, T2), and verifying the statement must equal verifying each equation
+    against the shared commitments -- the first equation (the reference's own statement, tests/prover.rs) holds,
+    the two with altered Gamma / constants do not, on both paths."""
+    import copy
+
+    c, mirror, crs = setup
+    case = c.golden["cases"][idx]
+    equ0, xvars, yvars = build(c, mirror, case)
+    equ1, equ2 = copy.deepcopy(equ0), copy.deepcopy(equ0)
+    equ1.gamma = [[c.fr(7 + 3 * i + j) for j in range(len(row))] for i, row in enumerate(equ0.gamma)]
+    equ2.a_consts = list(reversed(equ0.a_consts)) if len(equ0.a_consts) > 1 else [equ0.a_consts[0] * 0]
+    equ2.gamma = [[c.fr(0) for _ in row] for row in equ0.gamma]
+    T1 = [[hex(0x1234567 + 17 * i + j)[2:] for j, _ in enumerate(row)] for i, row in enumerate(case["T"])]
+    T2 = [[hex(0xABCDEF01 + 5 * i + j)[2:] for j, _ in enumerate(row)] for i, row in enumerate(case["T"])]
+    st = mirror.Statement([equ0, equ1, equ2])
+    proof = st.commit_and_prove(xvars, yvars, crs, ReplayRng(c, [case["R"], case["S"], case["T"], T1, T2]))
+    # reference path: commitments, then Provable::prove per equation with the same draws
+    rng = ReplayRng(c, [case["R"], case["S"], case["T"], T1, T2])
+    kx, ky = equ0._kxky()
+    xc = (mirror.batch_commit_G1 if kx == 2 else mirror.batch_commit_scalar_to_B1)(xvars, crs, rng)
+    yc = (mirror.batch_commit_G2 if ky == 2 else mirror.batch_commit_scalar_to_B2)(yvars, crs, rng)
+    assert proof.xcoms == xc and proof.ycoms == yc
+    singles = [e.prove(xvars, yvars, xc, yc, crs, rng) for e in (equ0, equ1, equ2)]
+    assert rng.i == len(rng.q)
+    for got, want in zip(proof.equ_proofs, singles):
+        assert all((a == b).all() for a, b in zip(got.pi, want.pi))
+        assert all((a == b).all() for a, b in zip(got.theta, want.theta))
+        assert _mat_same(got.rand, want.rand)
+    verdicts = st.verify(proof, crs)
+    each = [e.verify(mirror.CProof(xc, yc, [pf]), crs) for e, pf in zip((equ0, equ1, equ2), singles)]
+    assert verdicts == each and verdicts[0] is True and verdicts[1] is False
+    # first equation's proof bytes are the golden fixture's
+    assert [c.com2_dec(v) for v in proof.equ_proofs[0].pi] == case["pi"]
+
+
+def _mat_same(a, b):
+    return len(a) == len(b) and all(len(x) == len(y) and all((p == q).all() for p, q in zip(x, y)) for x, y in zip(a, b))
+
+
 def test_generate_crs_structure(setup):
     """generator.rs:137-207: generators are non-degenerate, gt_gen = e(g1, g2), and the binding-key
     structure u[1] = t1 * u[0], v[1] = t2 * v[0] holds."""

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include "../groth_sahai_rs_amd/csrc/gs_params_bls12_381.h"
 #include "../groth_sahai_rs_amd/csrc/gs_pairing.cuh"
+#include "../groth_sahai_rs_amd/csrc/gs_coop.cuh"
 
 namespace gs {
 GS_ZERO_ONE(Bls12_381)
@@ -54,6 +55,24 @@ template <int WPE> __device__ __forceinline__ void miller_body(uint32_t* out, in
 #endif
 __global__ void __launch_bounds__(64, UB_WPE) k_miller_w1(uint32_t* out, int iters) { miller_body<1>(out, iters); }
 
+// (c) the existing 3-lane cooperative steps (gs_coop.cuh): 3 Granger-Scott squarings + 1 product by a base per
+// iteration = 3 x 6 + 27 = 45 Fq multiplications per LANE; 21 groups per wave
+__global__ void __launch_bounds__(64, UB_WPE) k_coop(uint32_t* out, int iters) {
+  int lane = threadIdx.x, j = lane % 3;
+  if (lane >= 63) return;
+  Fp4<C> acc = {seed_fp2(lane + 3), seed_fp2(lane + 5)};
+  Fp4<C> Bs[3];
+  for (int i = 0; i < 3; i++) Bs[i] = {seed_fp2(lane + 7 + i), seed_fp2(lane + 17 + i)};
+  CoopWave xw{lane - j};
+  for (int i = 0; i < iters; i++) {
+    c12_sqr_step(acc, j, xw);
+    c12_sqr_step(acc, j, xw);
+    c12_sqr_step(acc, j, xw);
+    c12_mul_step(acc, Bs, j, xw);
+  }
+  out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(acc.a.c0.v[0] + acc.b.c1.v[2]);
+}
+
 template <class K> void run(const char* name, K kern, int muls_per_iter, int iters, uint32_t* d) {
   hipDeviceProp_t pr;
   hipGetDeviceProperties(&pr, 0);
@@ -84,6 +103,7 @@ int main() {
   hipMalloc(&d, 64u * 4096 * 16);
   run("mul chain (2 mul + 1 sqr)", k_chain, 3, 20000, d);
   run(UB_WPE == 1 ? "miller body, 512 regs" : "miller body, 256 regs", k_miller_w1, 114, 400, d);
+  run(UB_WPE == 1 ? "coop steps (45/lane), 512 regs" : "coop steps (45/lane), 256 regs", k_coop, 45, 1000, d);
   hipError_t e = hipDeviceSynchronize();
   printf("status: %s\n", hipGetErrorString(e));
   return 0;
