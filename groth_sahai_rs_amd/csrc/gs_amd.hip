@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -452,17 +453,52 @@ static void build_side(SidePlan& sp, bool want_coms, int nv, int nc, bool group,
 
 // the reduction launch of a side, kept back so that the caller can run the two sides' reductions side by side
 struct RedLaunch {
-  std::string name;
-  const RedTask* dred = nullptr;
+  std::string name, tag;
+  std::vector<RedTask> hred;  // host copy: long runs are folded in parallel first (run_red)
   const void* part = nullptr;
   size_t nred = 0;
   int nslots = 0;
   OutTab outs;
 };
+constexpr uint32_t RED_FOLD_K = 8, RED_RUN_MAX = 16;
 template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLaunch& r) {
-  c->work_hint = N * (uint64_t)r.nslots;  // partial sums folded
-  return launch(c, r.name.c_str(), k_red<C, F>, N * r.nred, 64, N * r.nred, (int)r.nred, r.dred,
-                (const Jac<F>*)r.part, r.nslots, r.outs);
+  std::vector<RedTask> red = r.hred;
+  const Jac<F>* part = (const Jac<F>*)r.part;
+  int nslots = r.nslots;
+  // segmented K-ary tree: while a component of some output still sums more than RED_RUN_MAX slots, fold runs of K
+  for (int level = 0;; level++) {
+    uint32_t longest = 0;
+    for (const RedTask& t : red) {
+      longest = std::max(longest, t.e0 - t.b0);
+      longest = std::max(longest, t.e1 - t.b1);
+    }
+    if (longest <= RED_RUN_MAX) break;
+    std::vector<FoldTask> ft;
+    uint32_t next = 0;
+    auto fold_range = [&](uint32_t& b, uint32_t& e) {
+      uint32_t nb = next;
+      for (uint32_t lo = b; lo < e; lo += RED_FOLD_K) ft.push_back(FoldTask{lo, std::min(lo + RED_FOLD_K, e), next++, 0});
+      b = nb;
+      e = next;
+    };
+    for (RedTask& t : red) {
+      fold_range(t.b0, t.e0);
+      fold_range(t.b1, t.e1);
+    }
+    const FoldTask* dft;
+    RC(upload(c, (r.tag + ".fold").c_str(), ft, &dft));
+    void* out;
+    RC(scratch(c, (r.tag + (level & 1 ? ".fold1" : ".fold0")).c_str(), N * (size_t)next * sizeof(Jac<F>), &out));
+    c->work_hint = N * (uint64_t)nslots;
+    RC(launch(c, (std::string("k_slot_fold") + r.tag).c_str(), k_slot_fold<C, F>, N * ft.size(), 64, N * ft.size(),
+              (int)ft.size(), dft, part, nslots, (Jac<F>*)out, (int)next));
+    part = (const Jac<F>*)out;
+    nslots = (int)next;
+  }
+  const RedTask* dred;
+  RC(upload(c, (r.tag + ".red").c_str(), red, &dred));
+  c->work_hint = N * (uint64_t)nslots;  // partial sums folded
+  return launch(c, r.name.c_str(), k_red<C, F>, N * r.nred, 64, N * r.nred, (int)r.nred, dred, part, nslots, r.outs);
 }
 template <class C, class F>
 static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
@@ -471,10 +507,8 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
   std::string t(tag);
   const VarTask* dvar;
   const FixTask* dfix;
-  const RedTask* dred;
   RC(upload(c, (t + ".var").c_str(), sp.var, &dvar));
   RC(upload(c, (t + ".fix").c_str(), sp.fix, &dfix));
-  RC(upload(c, (t + ".red").c_str(), sp.red, &dred));
   void* part;
   RC(scratch(c, (t + ".part").c_str(), N * sp.nslots * sizeof(Jac<F>), &part));
   // fork: the variable-base kernel goes to `vstream` (if any) while the fixed-base one stays on the side's stream
@@ -514,7 +548,8 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
   }
   RedLaunch r;
   r.name = std::string("k_red") + tag;
-  r.dred = dred;
+  r.tag = t;
+  r.hred = sp.red;
   r.part = part;
   r.nred = sp.red.size();
   r.nslots = sp.nslots;
@@ -993,15 +1028,42 @@ template <class C> struct Impl {
     void* mpart;
     RC(verify_front(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, vp, &mpart, shared));
     int ntask = (int)vp.mt.size();
+    // large arities: hundreds of Miller partials per cell -- fold runs of K in parallel until k_final's own serial
+    // product is short (segmented K-ary tree in GT)
+    CellMap cm = vp.cm;
+    {
+      const int K = 8;
+      for (int level = 0;; level++) {
+        int longest = 0;
+        for (int q = 0; q < 4; q++) longest = std::max(longest, cm.hi[q] - cm.lo[q]);
+        if (longest <= 2 * K) break;
+        CellMap out;
+        int nt_out = 0, runs_max = (longest + K - 1) / K;
+        for (int q = 0; q < 4; q++) {
+          out.lo[q] = nt_out;
+          nt_out += (cm.hi[q] - cm.lo[q] + K - 1) / K;
+          out.hi[q] = nt_out;
+          out.sub[q] = 0;
+        }
+        void* folded;
+        RC(scratch(c, level & 1 ? "verify.mfold1" : "verify.mfold0", 2 * N * (size_t)nt_out * sizeof(GT), &folded));
+        size_t total = N * 4 * (size_t)runs_max;
+        RC(launch(c, "k_cell_fold", k_cell_fold<C>, total, 64, total, runs_max, ntask, cm, (const GT*)mpart, K, nt_out, out,
+                  (GT*)folded));
+        mpart = folded;
+        ntask = nt_out;
+        cm = out;
+      }
+    }
     void* cellok;
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
     // one lane per final exponentiation once that fills the chip, 3-lane groups (21 per wave) below that
     size_t coop_waves = (N * 4 + 20) / 21;
     if (c->coop_fe == 2 || (c->coop_fe == 1 && coop_waves <= c->simd_slots))
-      RC(launch(c, "k_final.coop", k_final_coop<C>, coop_waves * 63, 63, N, ntask, vp.cm, (const GT*)mpart,
+      RC(launch(c, "k_final.coop", k_final_coop<C>, coop_waves * 63, 63, N, ntask, cm, (const GT*)mpart,
                 ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
     else
-      RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, vp.cm,
+      RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, cm,
                 (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
     RC(launch(c, "k_and4", k_and4, N, 64, N, (const uint8_t*)cellok, ok));
     return GS_OK;

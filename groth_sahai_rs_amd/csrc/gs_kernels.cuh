@@ -536,6 +536,25 @@ __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, con
   aff_store<C>(o + AFFB(C, F), a1);
 }
 
+// Large arities (benches/bench.rs:451-498, m = n = 334): an output is the sum of hundreds of partial slots.  k_red
+// folds its slots serially in ONE lane, so the host first folds runs of K slots in parallel (one lane per run), and
+// again, until every run k_red sees is short: a segmented K-ary tree reduction.
+struct FoldTask {
+  uint32_t lo, hi, dst, pad;  // dst slot (in the output array) <- sum of input slots [lo, hi)
+};
+template <class C, class F>
+__global__ void __launch_bounds__(64, GS_WPE) k_slot_fold(size_t total, int ntask, const FoldTask* tasks, const Jac<F>* in,
+                                                          int ns_in, Jac<F>* out, int ns_out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  size_t e = g / ntask;
+  FoldTask t = tasks[g % ntask];
+  const Jac<F>* P = in + e * ns_in;
+  Jac<F> s = P[t.lo];
+  for (uint32_t i = t.lo + 1; i < t.hi; i++) jac_add(s, s, P[i]);
+  out[e * ns_out + t.dst] = s;
+}
+
 // --------------------------------------------------------------------------
 // pairing side
 // --------------------------------------------------------------------------
@@ -608,6 +627,25 @@ template <class C> GS_HD_NOINLINE void cell_product(Fp12<C>& f, const Fp12<C>* m
   f = mpart[2 * (e * ntask + lo) + a];
   for (int i = lo + 1; i < hi; i++) f12_mul(f, f, mpart[2 * (e * ntask + i) + a]);
 }
+// Large arities: a cell has hundreds of Miller partials.  One lane per (equation, cell, run of K partials) multiplies
+// its run; repeated by the host until k_final's own serial product is short (segmented K-ary tree in GT).
+// Output layout = cell_product's: out[2 * (e * nt_out + cm_out.lo[c] + run) + 0].
+template <class C>
+__global__ void __launch_bounds__(64, GS_WPE) k_cell_fold(size_t total, int runs_max, int ntask_in, CellMap cm_in,
+                                                          const Fp12<C>* in, int K, int nt_out, CellMap cm_out,
+                                                          Fp12<C>* out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  int run = (int)(g % runs_max);
+  int c = (int)((g / runs_max) & 3);
+  size_t e = g / ((size_t)runs_max * 4);
+  int lo = cm_in.lo[c] + run * K, hi = lo + K < cm_in.hi[c] ? lo + K : cm_in.hi[c], a = cm_in.sub[c];
+  if (lo >= cm_in.hi[c]) return;
+  Fp12<C> f = in[2 * (e * ntask_in + lo) + a];
+  for (int i = lo + 1; i < hi; i++) f12_mul(f, f, in[2 * (e * ntask_in + i) + a]);
+  out[2 * (e * nt_out + cm_out.lo[c] + run)] = f;
+}
+
 template <class C>
 __global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart,
                                               const uint8_t* target, uint8_t* cellok) {

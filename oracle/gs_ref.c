@@ -28,6 +28,7 @@
  *   gcc -O2 -DCURVE_BLS12_381 ... -> oracle/libgs_ref_bls12_381.so
  */
 #include <pthread.h>
+#include <unistd.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -645,13 +646,35 @@ static void com1_left_mul(com1* out, const fr* lhs, int rows, int cols, const co
     out[i] = acc;
   }
 }
-static void com2_left_mul(com2* out, const fr* lhs, int rows, int cols, const com2* col) {
-  for (int i = 0; i < rows; i++) {
+static void com2_left_mul_rows(com2* out, const fr* lhs, int r0, int r1, int cols, const com2* col) {
+  for (int i = r0; i < r1; i++) {
     com2 acc;
     memset(&acc, 0, sizeof acc);
     for (int k = 0; k < cols; k++) { com2 t; com2_smul(&t, &col[k], &lhs[i * cols + k]); com2_add(&acc, &acc, &t); }
     out[i] = acc;
   }
+}
+/* Large statements (the reference's 334 x 334 bench shape, benches/bench.rs:451-498): the rows of Gamma * d are
+ * independent, exactly as in the reference's Rayon branch (data_structures.rs:707-729) -- same per-term evaluation,
+ * rows spread over the host cores so that the test finishes in seconds instead of minutes. */
+typedef struct { com2* out; const fr* lhs; int r0, r1, cols; const com2* col; } lm2_job;
+static void* lm2_worker(void* a) { lm2_job* j = (lm2_job*)a; com2_left_mul_rows(j->out, j->lhs, j->r0, j->r1, j->cols, j->col); return 0; }
+static void com2_left_mul(com2* out, const fr* lhs, int rows, int cols, const com2* col) {
+  long work = (long)rows * cols;
+  int nt = 1;
+  if (work >= 2048) {
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    nt = (int)(nc < 1 ? 1 : nc > 32 ? 32 : nc);
+    if (nt > rows) nt = rows;
+  }
+  if (nt <= 1) { com2_left_mul_rows(out, lhs, 0, rows, cols, col); return; }
+  pthread_t th[32];
+  lm2_job jobs[32];
+  for (int t = 0; t < nt; t++) {
+    jobs[t] = (lm2_job){out, lhs, (int)((long)rows * t / nt), (int)((long)rows * (t + 1) / nt), cols, col};
+    pthread_create(&th[t], 0, lm2_worker, &jobs[t]);
+  }
+  for (int t = 0; t < nt; t++) pthread_join(th[t], 0);
 }
 static void fr_matmul(fr* out, const fr* a, int ar, int ac, const fr* b, int bc) { /* (ar x ac)(ac x bc) */
   for (int i = 0; i < ar; i++) for (int j = 0; j < bc; j++) {

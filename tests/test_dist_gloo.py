@@ -34,6 +34,8 @@ WORKER = textwrap.dedent(
     failed = sum(1 for i in range(lo, hi) if i == 777)
     total = allreduce_failures(failed)
     assert total == 1, total
+    # the bench passes the count as a tensor (no host round trip before the collective)
+    assert allreduce_failures(torch.tensor(failed), device="cpu") == 1
     acc = torch.full((1152,), r + 1, dtype=torch.uint8)   # stand-in for the 2 x GT accumulator bytes
     outs = allgather_accumulators(acc)
     assert [int(o[0]) for o in outs] == list(range(1, w + 1))   # rank order on every rank
