@@ -12,6 +12,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -75,6 +76,7 @@ struct gs_ctx {
   std::map<std::string, DevBuf> scratch;
   std::map<std::string, PlanEntry> plans;  // task tables by (name, size, content hash); content compared on a hit
   uint64_t plan_clock = 0;
+  std::map<std::string, std::pair<bool, double>> miller_choice;  // planner decisions by (shape, N, overrides)
   // profiling
   bool prof = false;
   std::map<std::string, ProfEntry> prof_map;
@@ -159,19 +161,30 @@ static void chunk_tasks(std::vector<MillerTask>& mt, const std::vector<PairRef>&
   size_t P = pr.size();
   if (P == 0) return;
   std::vector<size_t> order;
+  double total = 0;
   for (size_t i = 0; i < P; i++)
     if (!pair_fixed(lt, pr[i])) order.push_back(i);
   for (size_t i = 0; i < P; i++)
     if (pair_fixed(lt, pr[i])) order.push_back(i);
-  for (size_t nt = (P + MILLER_CH - 1) / MILLER_CH; nt <= P; nt++) {
+  for (size_t i = 0; i < P; i++) total += pair_fixed(lt, pr[i]) ? mc.fix : mc.var;
+  // no fewer tasks than the capacity or the budget allow (large arities have hundreds of pairs per cell: start at the
+  // bound instead of walking up to it, and place with a heap: O(P log P) per attempt)
+  size_t nt0 = (P + MILLER_CH - 1) / MILLER_CH;
+  if (budget > 0) nt0 = std::max(nt0, (size_t)(total / budget));
+  nt0 = std::min(std::max(nt0, (size_t)1), P);
+  for (size_t nt = nt0; nt <= P; nt++) {
     std::vector<double> load(nt, 0.0);
     std::vector<std::vector<size_t>> members(nt);
+    typedef std::pair<double, size_t> Slot;  // (load, task): lightest task that still has room first
+    std::priority_queue<Slot, std::vector<Slot>, std::greater<Slot>> heap;
+    for (size_t t = 0; t < nt; t++) heap.push(Slot(0.0, t));
     for (size_t idx : order) {
-      size_t best = nt;
-      for (size_t t = 0; t < nt; t++)
-        if (members[t].size() < (size_t)MILLER_CH && (best == nt || load[t] < load[best])) best = t;
+      Slot sl = heap.top();
+      heap.pop();
+      size_t best = sl.second;
       members[best].push_back(idx);
       load[best] += pair_fixed(lt, pr[idx]) ? mc.fix : mc.var;
+      if (members[best].size() < (size_t)MILLER_CH) heap.push(Slot(load[best], best));
     }
     double mx = 0;
     for (double l : load) mx = l > mx ? l : mx;
@@ -833,8 +846,11 @@ template <class C> struct Impl {
   // Q arrays: 0 ycoms, 1 B, 2 crs G2 consts, 3 pi, 4 target (MSMEG2)
   static void build_verify(VerifyPlan& vp, int curve, int ty, int m, int n, const PoolMap& pm, double budget, bool twin,
                            int tm, bool lt) {
+    build_verify_g1(vp, ty, m, n, pm, tm);
+    build_verify_miller(vp, curve, ty, m, n, budget, twin, lt);
+  }
+  static void build_verify_g1(VerifyPlan& vp, int ty, int m, int n, const PoolMap& pm, int tm) {
     bool xg = x_is_group(ty), yg = y_is_group(ty);
-    int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     // ---- G1-side points: PA_j.a = map_a_j.a + sum_i Gamma_ij c_i.a ;  PB.a = sum_i b_i c_i.a - lin_t
     // engine arrays: 0 = xcoms as 2m G1 points, 1 = A (group), 2 = target (MSMEG1)
     SidePlan& sp = vp.g1;
@@ -876,6 +892,10 @@ template <class C> struct Impl {
       vp.npa = n + 1;
     }
     sp.nslots = slot;
+  }
+  static void build_verify_miller(VerifyPlan& vp, int curve, int ty, int m, int n, double budget, bool twin, bool lt) {
+    bool xg = x_is_group(ty), yg = y_is_group(ty);
+    int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
     // ---- Miller tasks.  Pairs of cell (a, b): G1 argument = component a, G2 argument = component b.
     //  twin  : one task list per b, each lane takes `ch` (Q, P0, P1) triples and keeps two accumulators
     //          (lines of Q computed once) -- less total work, pays off once the chip is full;
@@ -938,19 +958,30 @@ template <class C> struct Impl {
     bool twin = false;
     double budget = 3 * 4621.0;
     {
-      double best = -1;
-      for (int tw = 0; tw < 2; tw++) {
-        if (c->miller_twin >= 0 && tw != c->miller_twin) continue;
-        for (double cand : miller_budgets(c, tw != 0)) {
-          VerifyPlan tmp;
-          build_verify(tmp, c->curve, ty, m, n, pm, cand, tw != 0, 1, c->line_tables);
-          double cost = miller_cost(c, N, tmp.mt, tw != 0);
-          if (best < 0 || cost < best) {
-            best = cost;
-            twin = tw != 0;
-            budget = cand;
+      // the choice depends on the shape, the batch size and the overrides only: remembered per context
+      char key[96];
+      snprintf(key, sizeof key, "%d.%d.%d.%zu.%d.%d.%d", ty, m, n, N, c->miller_twin, c->miller_ch, (int)c->line_tables);
+      auto hit = c->miller_choice.find(key);
+      if (hit != c->miller_choice.end()) {
+        twin = hit->second.first;
+        budget = hit->second.second;
+      } else {
+        double best = -1;
+        for (int tw = 0; tw < 2; tw++) {
+          if (c->miller_twin >= 0 && tw != c->miller_twin) continue;
+          for (double cand : miller_budgets(c, tw != 0)) {
+            VerifyPlan tmp;
+            build_verify_miller(tmp, c->curve, ty, m, n, cand, tw != 0, c->line_tables);
+            double cost = miller_cost(c, N, tmp.mt, tw != 0);
+            if (best < 0 || cost < best) {
+              best = cost;
+              twin = tw != 0;
+              budget = cand;
+            }
           }
         }
+        if (c->miller_choice.size() > 4096) c->miller_choice.clear();
+        c->miller_choice[key] = std::make_pair(twin, budget);
       }
     }
     build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false), c->line_tables);

@@ -66,7 +66,8 @@ template <class C> GS_HD Fp2<C> mul(const Fp2<C>& a, const Fp2<C>& b) {
 // inputs with A <= 2 (e.g. one sum of two N values)
 template <class C> GS_HD Fp2<C> mul_l2(const Fp2<C>& a, const Fp2<C>& b) {
   Fq<C> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1);
-  Fq<C> s = mul(norm(add(a.c0, a.c1)), norm(add(b.c0, b.c1)));
+  // one carry round is enough: (A <= 4) x (A ~ 1) stays inside the multiplier's A*B <= 8 contract
+  Fq<C> s = mul(add(a.c0, a.c1), norm(add(b.c0, b.c1)));
   return {sub(v0, v1), norm(sub(sub(s, v0), v1))};
 }
 template <class C> GS_HD Fp2<C> sqr(const Fp2<C>& a) {
@@ -75,7 +76,7 @@ template <class C> GS_HD Fp2<C> sqr(const Fp2<C>& a) {
 }
 template <class C> GS_HD Fp2<C> sqr_l2(const Fp2<C>& a) {
   Fq<C> t = mul(a.c0, a.c1);
-  return {mul(norm(add(a.c0, a.c1)), norm(sub(a.c0, a.c1))), norm(dbl(t))};
+  return {mul(add(a.c0, a.c1), norm(sub(a.c0, a.c1))), norm(dbl(t))};
 }
 template <class C> GS_HD Fp2<C> mul_fp(const Fp2<C>& a, const Fq<C>& k) { return {mul(a.c0, k), mul(a.c1, k)}; }
 // lazy: A_out = (XI_A + 1) * A_in

@@ -26,14 +26,17 @@ __device__ Fq<C> seed_fq(uint32_t s) {
 __device__ Fp2<C> seed_fp2(uint32_t s) { return {seed_fq(s), seed_fq(s * 7 + 1)}; }
 
 // (a) bare chain: 2 multiplications + 1 squaring per iteration
-__global__ void __launch_bounds__(64) k_chain(uint32_t* out, int iters) {
-  Fq<C> x = seed_fq(threadIdx.x + 1), y = seed_fq(threadIdx.x + 77);
+#ifndef UB_BLOCK
+#define UB_BLOCK 64
+#endif
+__global__ void __launch_bounds__(UB_BLOCK) k_chain(uint32_t* out, int iters) {
+  Fq<C> x = seed_fq(threadIdx.x % 64 + 1), y = seed_fq(threadIdx.x % 64 + 77);
   for (int i = 0; i < iters; i++) {
     x = mul(x, y);
     y = sqr(y);
     y = mul(y, x);
   }
-  out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(x.v[0] + y.v[3]);
+  out[blockIdx.x * UB_BLOCK + threadIdx.x] = (uint32_t)(x.v[0] + y.v[3]);
 }
 
 // (b) Miller inner loop on one accumulator: square, two sparse line products (36 + 2 x 39 = 114 Fq multiplications)
@@ -48,17 +51,17 @@ template <int WPE> __device__ __forceinline__ void miller_body(uint32_t* out, in
     f12_mul_by_014(f, l0, l1, l4);
     f12_mul_by_014(f, l1, l4, l0);
   }
-  out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(f.c0.c0.c0.v[0] + f.c1.c1.c1.v[2]);
+  out[blockIdx.x * UB_BLOCK + threadIdx.x] = (uint32_t)(f.c0.c0.c0.v[0] + f.c1.c1.c1.v[2]);
 }
 #ifndef UB_WPE
 #define UB_WPE 1
 #endif
-__global__ void __launch_bounds__(64, UB_WPE) k_miller_w1(uint32_t* out, int iters) { miller_body<1>(out, iters); }
+__global__ void __launch_bounds__(UB_BLOCK, UB_WPE) k_miller_w1(uint32_t* out, int iters) { miller_body<1>(out, iters); }
 
 // (c) the existing 3-lane cooperative steps (gs_coop.cuh): 3 Granger-Scott squarings + 1 product by a base per
 // iteration = 3 x 6 + 27 = 45 Fq multiplications per LANE; 21 groups per wave
-__global__ void __launch_bounds__(64, UB_WPE) k_coop(uint32_t* out, int iters) {
-  int lane = threadIdx.x, j = lane % 3;
+__global__ void __launch_bounds__(UB_BLOCK, UB_WPE) k_coop(uint32_t* out, int iters) {
+  int lane = threadIdx.x % 64, j = lane % 3;
   if (lane >= 63) return;
   Fp4<C> acc = {seed_fp2(lane + 3), seed_fp2(lane + 5)};
   Fp4<C> Bs[3];
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(64, UB_WPE) k_coop(uint32_t* out, int iters) {
     c12_sqr_step(acc, j, xw);
     c12_mul_step(acc, Bs, j, xw);
   }
-  out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(acc.a.c0.v[0] + acc.b.c1.v[2]);
+  out[blockIdx.x * UB_BLOCK + threadIdx.x] = (uint32_t)(acc.a.c0.v[0] + acc.b.c1.v[2]);
 }
 
 template <class K> void run(const char* name, K kern, int muls_per_iter, int iters, uint32_t* d) {
@@ -82,11 +85,11 @@ template <class K> void run(const char* name, K kern, int muls_per_iter, int ite
   hipEventCreate(&e1);
   printf("%-34s", name);
   for (int wps = 1; wps <= 4; wps *= 2) {
-    int blocks = simds * wps;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, d, 2);
+    int blocks = simds * wps * 64 / UB_BLOCK;  // UB_BLOCK = 256: one wave of a block per SIMD of its CU (balanced)
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(UB_BLOCK), 0, 0, d, 2);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, d, iters);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(UB_BLOCK), 0, 0, d, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
