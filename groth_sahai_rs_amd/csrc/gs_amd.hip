@@ -201,6 +201,16 @@ static void chunk_tasks(std::vector<MillerTask>& mt, const std::vector<PairRef>&
     return;
   }
 }
+// serial cost (in units of `unit`) of reducing `n` partial results: runs of 8 folded in parallel while more than 16
+// are left (k_cell_fold / k_slot_fold), the rest by the consuming lane
+static double fold_cost(double n, double unit) {
+  double c = 0;
+  while (n > 16.0) {
+    c += 8.0 * unit;
+    n = (double)(size_t)((n + 7.0) / 8.0);
+  }
+  return c + n * unit;
+}
 static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTask>& mt, bool twin) {
   const MCost mc = mcost(c->curve, twin);
   double lane = 0;
@@ -209,12 +219,13 @@ static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTas
     for (int q = 0; q < t.np; q++) l += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix : mc.var;
     lane = l > lane ? l : lane;
   }
-  double waves = (double)mt.size() * (double)((N + 63) / 64);
+  double waves = (double)(size_t)(((double)mt.size() * (double)N + 63.0) / 64.0);  // lanes are contiguous (task-major)
   double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
   if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);  // whole rounds matter while there are few of them
-  // + the k_final lane that multiplies a cell's partials together (54 Fq multiplications each; large arities)
+  // + the lanes that multiply a cell's partials together (54 Fq multiplications each): k_final's own serial product
+  // up to 16 of them, above that K-ary tree levels of 8 (k_cell_fold; large arities)
   double per_cell = (double)mt.size() * (twin ? 2.0 : 1.0) / 4.0;
-  return rounds * lane + per_cell * 54.0;
+  return rounds * lane + fold_cost(per_cell, 54.0);
 }
 // lane-cost budgets worth trying: a variable + f fixed pairs
 static std::vector<double> miller_budgets(const gs_ctx* c, bool twin) {
@@ -409,7 +420,7 @@ static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
     double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
     if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);
     // + the lane of k_red that folds the ng partial sums of an output (matters for large arities)
-    double cost = rounds * (D + P * eff) + (double)ng * (g2 ? 29.0 + 14.0 : 16.0);
+    double cost = rounds * (D + P * eff) + fold_cost((double)ng, g2 ? 29.0 + 14.0 : 16.0);
     if (best < 0 || cost < best) {
       best = cost;
       best_tm = eff;
