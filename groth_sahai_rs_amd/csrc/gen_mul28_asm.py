@@ -98,6 +98,85 @@ def gen_sqr(L):
     )
 
 
+# ---- the same bodies as SUBROUTINES reached with s_swappc_b64 from an inline-asm "call" --------------------------------
+# A C++ function call costs more than its branch: every non-kernel function starts with s_waitcnt vmcnt(0) lgkmcnt(0)
+# (the callee cannot know what is in flight), so each of the ~10^5 multiplier calls of a pairing lane also waited for
+# every spill store and operand load its caller had just issued.  Calling the multiplier from an asm statement with
+# FIXED operand registers keeps the hardware call (s_swappc_b64 / s_setpc_b64) and drops the wait: the compiler sees
+# an instruction that reads v0..v(2L-1) and the modulus in s40.., writes v(2L)..v(3L-1) and clobbers three VGPRs, vcc
+# and s[34:35], and inserts only the waits those registers need.  The subroutine bodies live behind labels inside a
+# never-executed holder function (file-scope asm is not emitted for the device).
+def sub_body(L, square):
+    A = lambda i: "v%d" % i
+    B = lambda i: "v%d" % (L + i)
+    R = lambda i: "v%d" % (2 * L + i)
+    P = lambda i: "s%d" % (40 + i)
+    INV = "s%d" % (40 + L)
+    ACC, LO = "v[%d:%d]" % (3 * L, 3 * L + 1), "v%d" % (3 * L)
+    out = []
+    if square:  # d = 2a in the (clobbered) b registers
+        for i in range(L):
+            out.append("v_lshlrev_b32 %s, 1, %s" % (B(i), A(i)))
+    first = True
+    for k in range(2 * L - 1):
+        for i in range(max(0, k - L + 1), min(k, L - 1) + 1):
+            j = k - i
+            if square and i > j:
+                continue
+            y = (A(j) if i == j else B(j)) if square else B(j)
+            out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (ACC, A(i), y, "0" if first else ACC))
+            first = False
+        for i in range(max(0, k - L + 1), min(k - 1, L - 1) + 1):
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, R(i), P(k - i), ACC))
+        if k < L:
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R(k), LO, INV))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R(k), R(k)))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, R(k), P(0), ACC))
+        else:
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R(k - L), LO))
+        out.append("v_ashrrev_i64 %s, 28, %s" % (ACC, ACC))
+    out.append("v_mov_b32 %s, %s" % (R(L - 1), LO))
+    out.append("s_setpc_b64 s[34:35]")
+    return out
+
+
+def gen_calls(L):
+    NL = "\\n\\t"  # the two escapes as they must appear inside the C string literal
+    o = []
+    for name in ("mul", "sqr"):
+        o.append('extern "C" __device__ void gs_%s28_sub_%d();' % (name, L))
+    body = ["s_branch .Lgs_skip%d_%%=" % L]
+    for name, sq in (("mul", False), ("sqr", True)):
+        sym = "gs_%s28_sub_%d" % (name, L)
+        body += [".p2align 8", ".globl %s" % sym, ".type %s,@function" % sym, sym + ":"] + sub_body(L, sq)
+    body.append(".Lgs_skip%d_%%=:" % L)
+    o.append("// never executed: carries the subroutines' code (their labels are the symbols declared above)")
+    o.append('extern "C" __device__ __attribute__((used, noinline)) void gs_fq28_sub_holder_%d() {' % L)
+    o.append('  asm volatile("%s" ::: "memory");' % NL.join(body))
+    o.append("}")
+    for name, sq in (("mul", False), ("sqr", True)):
+        outs = ", ".join('"={v%d}"(r[%d])' % (2 * L + i, i) for i in range(L))
+        ins = ", ".join('"{v%d}"(a[%d])' % (i, i) for i in range(L))
+        nin = L
+        if not sq:
+            ins += ", " + ", ".join('"{v%d}"(b[%d])' % (L + i, i) for i in range(L))
+            nin += L
+        ins += ", " + ", ".join('"{s%d}"(C::P28[%d])' % (40 + i, i) for i in range(L)) + ', "{s%d}"(C::P28_INV)' % (40 + L)
+        nin += L + 1
+        ins += ', "s"((uint64_t)(uintptr_t)&gs_%s28_sub_%d)' % (name, L)
+        clob = ['"v%d"' % (3 * L + i) for i in range(3)] + ['"vcc"', '"s34"', '"s35"']
+        if sq:
+            clob += ['"v%d"' % (L + i) for i in range(L)]
+        sig = "const int32_t (&a)[%d]" % L + ("" if sq else ", const int32_t (&b)[%d]" % L)
+        o.append("template <class C> __device__ __forceinline__ void %s28_call_%d(int32_t (&r)[%d], %s) {" % (name, L, L, sig))
+        o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (L + nin))
+        o.append("      : %s" % outs)
+        o.append("      : %s" % ins)
+        o.append("      : %s);" % ", ".join(clob))
+        o.append("}")
+    return "\n".join(o)
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     o = ["// GENERATED by gen_mul28_asm.py -- do not edit.  (included inside namespace gs)"]
@@ -108,6 +187,11 @@ def main():
         src, cnt = gen_sqr(L)
         o.append("// squaring, L = %d: %d instructions" % (L, cnt))
         o.append(src)
+    o.append("#if !defined(GS_NO_ASM_CALL)")
+    for L in (14, 10):
+        o.append("// ---- subroutine form, L = %d" % L)
+        o.append(gen_calls(L))
+    o.append("#endif")
     with open(os.path.join(here, "gs_mul28_asm.h"), "w") as f:
         f.write("\n".join(o) + "\n")
     print("wrote gs_mul28_asm.h")

@@ -248,6 +248,16 @@ template <class C> GS_HD Fq28<C> mul(const Fq28<C>& a, const Fq28<C>& b) {
   mul28_generic<C, limb_t>(rr.v, a.v, b.v);
   return rr;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM) && !defined(GS_NO_ASM_CALL)
+  // the multiplier as a SUBROUTINE reached from an asm statement with fixed operand registers (gs_mul28_asm.h,
+  // "subroutine form"): the hardware call without a C++ call's s_waitcnt vmcnt(0) at the callee's entry
+  Fq28<C> r;
+  if constexpr (C::L == 14)
+    mul28_call_14<C>(r.v, a.v, b.v);
+  else
+    mul28_call_10<C>(r.v, a.v, b.v);
+  return r;
+#else
   i32x16 av = 0, bv = 0;
 #pragma unroll
   for (int i = 0; i < C::L; i++) {
@@ -259,6 +269,7 @@ template <class C> GS_HD Fq28<C> mul(const Fq28<C>& a, const Fq28<C>& b) {
 #pragma unroll
   for (int i = 0; i < C::L; i++) r.v[i] = rv[i];
   return r;
+#endif
 }
 // squaring: its own out-of-line body on the device (L(L+1)/2 product mads against the doubled operand instead of
 // L^2, and one operand to marshal instead of two); same result and contract as mul(a, a)
@@ -287,6 +298,13 @@ template <class C> GS_HD_NOINLINE i32x16 sqr28_vec(i32x16 a) { return sqr28_body
 template <class C> GS_HD Fq28<C> sqr(const Fq28<C>& a) {
 #if defined(GS_FQ28_CHECK)
   return mul(a, a);
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM) && !defined(GS_NO_ASM_CALL)
+  Fq28<C> r;
+  if constexpr (C::L == 14)
+    sqr28_call_14<C>(r.v, a.v);
+  else
+    sqr28_call_10<C>(r.v, a.v);
+  return r;
 #else
   i32x16 av = 0;
 #pragma unroll
@@ -361,7 +379,9 @@ template <class C> GS_HD Fq28<C> inv(const Fq28<C>& a) {
 
 // ---- boundary conversion ---------------------------------------------------------
 // canonical saturated limbs (N x u32, value < p) -> internal
-template <class C> GS_HD Fq28<C> fq_from_boundary(const uint32_t* w) {
+// (out of line: kernels call these at their edges only, and a kernel body with the multiplier's fixed-register
+// asm statements inlined into it crashes this LLVM's machine scheduler)
+template <class C> GS_HD_NOINLINE Fq28<C> fq_from_boundary(const uint32_t* w) {
   Fq28<C> t;
 #pragma unroll
   for (int i = 0; i < C::L; i++) {
@@ -378,7 +398,7 @@ template <class C> GS_HD Fq28<C> fq_from_boundary(const uint32_t* w) {
   return mul(t, k);
 }
 // internal -> canonical saturated limbs
-template <class C> GS_HD void fq_to_boundary(uint32_t* w, const Fq28<C>& a) {
+template <class C> GS_HD_NOINLINE void fq_to_boundary(uint32_t* w, const Fq28<C>& a) {
   Fq28<C> k;
 #pragma unroll
   for (int i = 0; i < C::L; i++) k.v[i] = C::K_OUT28[i];
