@@ -87,9 +87,15 @@ template <class C> GS_HD void f12_from_pairs(Fp12<C>& f, const Fp4<C> A[3]) {
   f.c1.c2 = A[2].b;
 }
 
-// One squaring / one multiplication by the base of the group's accumulator.  Out of line on purpose, like
-// f12_cyclo_sqr / f12_mul: each keeps its own working set in registers, the loop around them only holds `acc`.
-template <class C, class X> GS_HD_NOINLINE void c12_sqr_step(Fp4<C>& acc, int j, X& xch) {
+// One squaring / one multiplication by the base of the group's accumulator.  Out of line unless GS_FE_INLINE (with the
+// multiplier an asm statement rather than a call, the squaring step is better off inside the loop: `acc` stays in
+// registers from step to step).
+#if defined(GS_FE_INLINE)
+#define GS_C12 GS_HD
+#else
+#define GS_C12 GS_HD_NOINLINE
+#endif
+template <class C, class X> GS_C12 void c12_sqr_step(Fp4<C>& acc, int j, X& xch) {
   Fp4<C> t;
   fp4_sqr(t.a, t.b, acc.a, acc.b);
   Fp4<C> got = xch.swap12(t, j);
@@ -100,7 +106,7 @@ template <class C, class X> GS_HD_NOINLINE void c12_mul_step(Fp4<C>& acc, const 
   xch.gather(A, acc, j);
   acc = c12_mul_lane(A, Bs);
 }
-template <class C> GS_HD_NOINLINE void c12_vreduce_step(Fp4<C>& acc) { acc = fp4_vreduce(acc); }
+template <class C> GS_C12 void c12_vreduce_step(Fp4<C>& acc) { acc = fp4_vreduce(acc); }
 
 // r = f^x on a 3-lane group; f is replicated on the lanes, so is r.  X provides
 //   Fp4 swap12(const Fp4& mine, int j)          value of lane (j == 0 ? 0 : 3 - j)

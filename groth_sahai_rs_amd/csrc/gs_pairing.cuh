@@ -86,7 +86,12 @@ template <class C> struct LineAcc {
   bool has = false;
   GS_HD void add(Fp12<C>& f, const Line<C>& l, const Aff<Fq<C>>& p) {
     Fp2<C> cx = mul_fp(l.lx, p.x), cy = mul_fp(l.ly, p.y);
-    if (!C::IS_BN) {  // measured on gfx950: pairing is a wash on BLS12-381 (the sparse product is the more
+#if defined(GS_LINES2_ALL)
+    constexpr bool pair_lines = true;
+#else
+    constexpr bool pair_lines = C::IS_BN;
+#endif
+    if (!pair_lines) {  // measured on gfx950: pairing is a wash on BLS12-381 (the sparse product is the more
       if (C::TWIST_M)  // register-friendly one) and takes 8 % off k_miller on BN254: lines are paired there only
         f12_mul_by_014(f, l.l0, cx, cy);
       else
@@ -326,7 +331,11 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f
   while (!((C::X_ABS >> top) & 1)) top--;
   int since = 0;
   for (int i = top - 1; i >= 0; i--) {
+#if defined(GS_FE_INLINE)
+    f12_cyclo_sqr_inl(acc, acc);
+#else
     f12_cyclo_sqr(acc, acc);
+#endif
     // Granger-Scott squaring feeds 2*z back linearly: values double per step; a
     // full multiplication contracts them again, otherwise reduce every 3rd step
     if ((C::X_ABS >> i) & 1) {

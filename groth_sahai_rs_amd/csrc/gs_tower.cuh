@@ -203,7 +203,9 @@ template <class C> GS_HD void f12_one(Fp12<C>& r) {
   r.c1.c1 = z;
   r.c1.c2 = z;
 }
-template <class C> GS_HD_NOINLINE void f12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {
+// GS_FE_INLINE: the x-power loops of the final exponentiation take the Fp12 product and the cyclotomic squaring
+// INLINE (the accumulator then stays in registers from one step to the next instead of crossing memory at every call)
+template <class C> GS_HD void f12_mul_inl(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {
   Fp6<C> t0, t1, sa, sb, m;
   f6_mul(t0, a.c0, b.c0);
   f6_mul(t1, a.c1, b.c1);
@@ -216,6 +218,7 @@ template <class C> GS_HD_NOINLINE void f12_mul(Fp12<C>& r, const Fp12<C>& a, con
   f6_mul_v(t1, t1);
   f6_addn(r.c0, t0, t1);
 }
+template <class C> GS_HD_NOINLINE void f12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) { f12_mul_inl(r, a, b); }
 // complex squaring: 2 Fp6 multiplications
 template <class C> GS_ML void f12_sqr(Fp12<C>& r, const Fp12<C>& a) {
   Fp6<C> v0, s0, s1, t;
@@ -365,7 +368,7 @@ template <class C> GS_HD void fp4_sqr(Fp2<C>& o0, Fp2<C>& o1, const Fp2<C>& a, c
   o0 = norm(sub(sub(m, ab), norm(mul_xi(ab))));
   o1 = norm(dbl(ab));
 }
-template <class C> GS_HD_NOINLINE void f12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& f) {
+template <class C> GS_HD void f12_cyclo_sqr_inl(Fp12<C>& r, const Fp12<C>& f) {
   Fp2<C> t0, t1, t2, t3, t4, t5;
   fp4_sqr(t0, t1, f.c0.c0, f.c1.c1);
   fp4_sqr(t2, t3, f.c1.c0, f.c0.c2);
@@ -388,6 +391,7 @@ template <class C> GS_HD_NOINLINE void f12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& 
   z = add(t3, f.c1.c2);
   r.c1.c2 = norm(add(dbl(z), t3));
 }
+template <class C> GS_HD_NOINLINE void f12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& f) { f12_cyclo_sqr_inl(r, f); }
 
 // bring every coefficient's VALUE back to ~[-p, p] (see vreduce in gs_fq28.cuh)
 template <class C> GS_HD_NOINLINE void f12_vreduce(Fp12<C>& f) {
