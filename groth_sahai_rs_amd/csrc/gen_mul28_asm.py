@@ -140,6 +140,90 @@ def sub_body(L, square):
     return out
 
 
+# ---- Fp2 product as ONE subroutine: schoolbook with lazy reduction ------------------------------------------------------
+#   c0 = a0 b0 - a1 b1,  c1 = a0 b1 + a1 b0
+# Each output is TWO product-scanning sums in ONE accumulator (a1 enters c0 negated) followed by ONE Montgomery
+# reduction: 4 L^2 + 2 L^2 mads = the mads of Karatsuba's three full products, but none of Karatsuba's 5 lazy
+# additions, no carry round on the result, a third less marshalling, and both outputs come out normalised.
+# Accumulator bound: 2 L products + L reduction terms per column, |a_i b_j| <= A_a A_b 2^56, so 28 A_a A_b + 14 < 128:
+# A_a A_b <= 4 -- a product of two sums of two normalised values (what mul_l2 is for) fits, with ~1.5 % to spare.
+# Registers: a0 v0.., a1 vL.., b0 v2L.., b1 v3L.. (preserved) -> c0 v4L.., c1 v5L..; -a1 v6L.., two accumulators and
+# nothing else; modulus in s40.. as for the single product.
+def sub_body_fp2(L):
+    A0 = lambda i: "v%d" % i
+    A1 = lambda i: "v%d" % (L + i)
+    B0 = lambda i: "v%d" % (2 * L + i)
+    B1 = lambda i: "v%d" % (3 * L + i)
+    R0 = lambda i: "v%d" % (4 * L + i)
+    R1 = lambda i: "v%d" % (5 * L + i)
+    N1 = lambda i: "v%d" % (6 * L + i)
+    P = lambda i: "s%d" % (40 + i)
+    INV = "s%d" % (40 + L)
+    AC0, LO0 = "v[%d:%d]" % (7 * L, 7 * L + 1), "v%d" % (7 * L)
+    AC1, LO1 = "v[%d:%d]" % (7 * L + 2, 7 * L + 3), "v%d" % (7 * L + 2)
+    out = []
+    for i in range(L):
+        out.append("v_sub_u32 %s, 0, %s" % (N1(i), A1(i)))
+    f0 = f1 = True
+    for k in range(2 * L - 1):
+        for i in range(max(0, k - L + 1), min(k, L - 1) + 1):
+            j = k - i
+            out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC0, A0(i), B0(j), "0" if f0 else AC0))
+            f0 = False
+            out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC1, A0(i), B1(j), "0" if f1 else AC1))
+            f1 = False
+            out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC0, N1(i), B1(j), AC0))
+            out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC1, A1(i), B0(j), AC1))
+        for i in range(max(0, k - L + 1), min(k - 1, L - 1) + 1):
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC0, R0(i), P(k - i), AC0))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC1, R1(i), P(k - i), AC1))
+        if k < L:
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R0(k), LO0, INV))
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R1(k), LO1, INV))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R0(k), R0(k)))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R1(k), R1(k)))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC0, R0(k), P(0), AC0))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC1, R1(k), P(0), AC1))
+        else:
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R0(k - L), LO0))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R1(k - L), LO1))
+        out.append("v_ashrrev_i64 %s, 28, %s" % (AC0, AC0))
+        out.append("v_ashrrev_i64 %s, 28, %s" % (AC1, AC1))
+    out.append("v_mov_b32 %s, %s" % (R0(L - 1), LO0))
+    out.append("v_mov_b32 %s, %s" % (R1(L - 1), LO1))
+    out.append("s_setpc_b64 s[34:35]")
+    return out
+
+
+def gen_fp2_call(L):
+    NLT = "\\n\\t"
+    sym = "gs_fp2mul28_sub_%d" % L
+    o = ['extern "C" __device__ void %s();' % sym]
+    body = ["s_branch .Lgs_skipf%d_%%=" % L, ".p2align 8", ".globl %s" % sym, ".type %s,@function" % sym, sym + ":"]
+    body += sub_body_fp2(L) + [".Lgs_skipf%d_%%=:" % L]
+    o.append('extern "C" __device__ __attribute__((used, noinline)) void gs_fp2mul28_sub_holder_%d() {' % L)
+    o.append('  asm volatile("%s" ::: "memory");' % NLT.join(body))
+    o.append("}")
+    outs = ", ".join('"={v%d}"(r0[%d])' % (4 * L + i, i) for i in range(L)) + ", " + \
+        ", ".join('"={v%d}"(r1[%d])' % (5 * L + i, i) for i in range(L))
+    ins = []
+    for base, nm in ((0, "a0"), (L, "a1"), (2 * L, "b0"), (3 * L, "b1")):
+        ins += ['"{v%d}"(%s[%d])' % (base + i, nm, i) for i in range(L)]
+    ins += ['"{s%d}"(C::P28[%d])' % (40 + i, i) for i in range(L)] + ['"{s%d}"(C::P28_INV)' % (40 + L)]
+    nin = 4 * L + L + 1
+    ins.append('"s"((uint64_t)(uintptr_t)&%s)' % sym)
+    clob = ['"v%d"' % (6 * L + i) for i in range(L + 4)] + ['"vcc"', '"s34"', '"s35"']
+    o.append("template <class C> __device__ __forceinline__ void fp2mul28_call_%d(int32_t (&r0)[%d], int32_t (&r1)[%d], "
+             "const int32_t (&a0)[%d], const int32_t (&a1)[%d], const int32_t (&b0)[%d], const int32_t (&b1)[%d]) {"
+             % (L, L, L, L, L, L, L))
+    o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (2 * L + nin))
+    o.append("      : %s" % outs)
+    o.append("      : %s" % ", ".join(ins))
+    o.append("      : %s);" % ", ".join(clob))
+    o.append("}")
+    return "\n".join(o), len(sub_body_fp2(L))
+
+
 def gen_calls(L):
     NL = "\\n\\t"  # the two escapes as they must appear inside the C string literal
     o = []
@@ -191,6 +275,9 @@ def main():
     for L in (14, 10):
         o.append("// ---- subroutine form, L = %d" % L)
         o.append(gen_calls(L))
+        src, cnt = gen_fp2_call(L)
+        o.append("// Fp2 product (schoolbook, lazy reduction), L = %d: %d instructions" % (L, cnt))
+        o.append(src)
     o.append("#endif")
     with open(os.path.join(here, "gs_mul28_asm.h"), "w") as f:
         f.write("\n".join(o) + "\n")

@@ -317,6 +317,80 @@ template <class C> GS_HD Fq28<C> sqr(const Fq28<C>& a) {
 #endif
 }
 
+// ---- Fp2 product kernel: schoolbook with lazy reduction ------------------------------------------------------------
+//   c0 = a0 b0 - a1 b1,  c1 = a0 b1 + a1 b0 : two product-scanning sums per accumulator, ONE Montgomery reduction per
+// output (gs_mul28_asm.h, "Fp2 product").  Same mads as Karatsuba's three full products, none of its five lazy
+// additions and no carry round on the result; both outputs normalised.  Contract: A_a * A_b <= 4 (2L products + L
+// reduction terms per column of a signed 64-bit accumulator); the CPU twin asserts it per column.
+template <class C, class T> GS_HD void fp2mul28_generic(T* r0, T* r1, const T* a0, const T* a1, const T* b0, const T* b1) {
+  constexpr int L = C::L;
+  uint32_t m0[L], m1[L];
+#if defined(GS_FQ28_CHECK)
+  __int128 acc0 = 0, acc1 = 0;
+#else
+  int64_t acc0 = 0, acc1 = 0;
+#endif
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (j < 0 || j >= L) continue;
+      acc0 += (int64_t)a0[i] * b0[j] - (int64_t)a1[i] * b1[j];
+      acc1 += (int64_t)a0[i] * b1[j] + (int64_t)a1[i] * b0[j];
+      if (j >= 1 && i < k) {
+        acc0 += (int64_t)(int32_t)m0[i] * C::P28[j];
+        acc1 += (int64_t)(int32_t)m1[i] * C::P28[j];
+      }
+    }
+#if defined(GS_FQ28_CHECK)
+    {
+      const __int128 lim = (__int128)1 << 63;
+      if (acc0 >= lim || acc0 < -lim || acc1 >= lim || acc1 < -lim) {
+        fprintf(stderr, "Fp2 product: column accumulator leaves the signed 64-bit range (A_a * A_b > 4)\n");
+        abort();
+      }
+    }
+#endif
+    if (k < L) {
+      m0[k] = ((((uint32_t)acc0) & (uint32_t)M28) * C::P28_INV) & (uint32_t)M28;
+      m1[k] = ((((uint32_t)acc1) & (uint32_t)M28) * C::P28_INV) & (uint32_t)M28;
+      acc0 += (int64_t)(int32_t)m0[k] * C::P28[0];
+      acc1 += (int64_t)(int32_t)m1[k] * C::P28[0];
+    } else {
+      r0[k - L] = (T)(((uint32_t)acc0) & (uint32_t)M28);
+      r1[k - L] = (T)(((uint32_t)acc1) & (uint32_t)M28);
+    }
+    acc0 >>= 28;
+    acc1 >>= 28;
+  }
+  r0[L - 1] = (T)acc0;
+  r1[L - 1] = (T)acc1;
+}
+template <class C> GS_HD void fp2mul28(Fq28<C>& r0, Fq28<C>& r1, const Fq28<C>& a0, const Fq28<C>& a1, const Fq28<C>& b0,
+                                       const Fq28<C>& b1) {
+#if defined(GS_FQ28_CHECK)
+  fq28_mul_counter().fetch_add(3, std::memory_order_relaxed);  // counted as the three products it replaces
+  for (const Fq28<C>* x : {&a0, &a1, &b0, &b1}) {
+    int64_t t = x->v[C::L - 1] < 0 ? -(int64_t)x->v[C::L - 1] : x->v[C::L - 1];
+    if (t >= (1 << 26)) {
+      fprintf(stderr, "Fp2 product: operand value out of range (top limb %lld)\n", (long long)t);
+      abort();
+    }
+  }
+  fp2mul28_generic<C, limb_t>(r0.v, r1.v, a0.v, a1.v, b0.v, b1.v);
+  GS_CHK_LIMBS(r0)
+  GS_CHK_LIMBS(r1)
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM) && !defined(GS_NO_ASM_CALL)
+  if constexpr (C::L == 14)
+    fp2mul28_call_14<C>(r0.v, r1.v, a0.v, a1.v, b0.v, b1.v);
+  else
+    fp2mul28_call_10<C>(r0.v, r1.v, a0.v, a1.v, b0.v, b1.v);
+#else
+  fp2mul28_generic<C, int32_t>(r0.v, r1.v, a0.v, a1.v, b0.v, b1.v);
+#endif
+}
+
 // ---- tests modulo p --------------------------------------------------------------
 // robust a == 0 (mod p) for any lazily reduced a within the mul contract: one
 // multiplication by 1 brings the value into (-p/2, 3p/2) with unique limbs, where

@@ -57,6 +57,16 @@ template <class C> GS_HD bool eq(const Fp2<C>& a, const Fp2<C>& b) { return is_z
 template <class C> GS_HD Fp2<C> select(bool c, const Fp2<C>& a, const Fp2<C>& b) {
   return {select(c, a.c0, b.c0), select(c, a.c1, b.c1)};
 }
+#if !defined(GS_FP2_KARATSUBA)
+// Schoolbook with lazy reduction as ONE multiplier kernel (fp2mul28, gs_fq28.cuh): inputs with A_a * A_b <= 4 -- N
+// inputs and sums of two N values alike -- both outputs N.
+template <class C> GS_HD Fp2<C> mul(const Fp2<C>& a, const Fp2<C>& b) {
+  Fp2<C> r;
+  fp2mul28<C>(r.c0, r.c1, a.c0, a.c1, b.c0, b.c1);
+  return r;
+}
+template <class C> GS_HD Fp2<C> mul_l2(const Fp2<C>& a, const Fp2<C>& b) { return mul(a, b); }
+#else
 // Karatsuba; inputs N, output N
 template <class C> GS_HD Fp2<C> mul(const Fp2<C>& a, const Fp2<C>& b) {
   Fq<C> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1);
@@ -70,6 +80,7 @@ template <class C> GS_HD Fp2<C> mul_l2(const Fp2<C>& a, const Fp2<C>& b) {
   Fq<C> s = mul(add(a.c0, a.c1), norm(add(b.c0, b.c1)));
   return {sub(v0, v1), norm(sub(sub(s, v0), v1))};
 }
+#endif
 template <class C> GS_HD Fp2<C> sqr(const Fp2<C>& a) {
   Fq<C> t = mul(a.c0, a.c1);
   return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), norm(dbl(t))};
