@@ -224,6 +224,83 @@ def gen_fp2_call(L):
     return "\n".join(o), len(sub_body_fp2(L))
 
 
+# ---- Fp2 squaring as one subroutine: c0 = (a0 + a1)(a0 - a1), c1 = (2 a0) a1, one reduction each -------------------------
+# a0 v0.., a1 vL.. (preserved) -> c0 v2L.., c1 v3L..; s = a0 + a1 v4L.., d = a0 - a1 v5L.., t = 2 a1 v6L..; inputs with
+# A <= 2 (L products of magnitude <= 8 2^56 plus L reduction terms per column).
+def sub_body_fp2sqr(L):
+    A0 = lambda i: "v%d" % i
+    A1 = lambda i: "v%d" % (L + i)
+    R0 = lambda i: "v%d" % (2 * L + i)
+    R1 = lambda i: "v%d" % (3 * L + i)
+    S = lambda i: "v%d" % (4 * L + i)
+    D = lambda i: "v%d" % (5 * L + i)
+    T = lambda i: "v%d" % (6 * L + i)
+    P = lambda i: "s%d" % (40 + i)
+    INV = "s%d" % (40 + L)
+    AC0, LO0 = "v[%d:%d]" % (7 * L, 7 * L + 1), "v%d" % (7 * L)
+    AC1, LO1 = "v[%d:%d]" % (7 * L + 2, 7 * L + 3), "v%d" % (7 * L + 2)
+    out = []
+    for i in range(L):
+        out.append("v_add_u32 %s, %s, %s" % (S(i), A0(i), A1(i)))
+        out.append("v_sub_u32 %s, %s, %s" % (D(i), A0(i), A1(i)))
+        out.append("v_lshlrev_b32 %s, 1, %s" % (T(i), A1(i)))
+    f0 = f1 = True
+    for k in range(2 * L - 1):
+        for i in range(max(0, k - L + 1), min(k, L - 1) + 1):
+            j = k - i
+            out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC0, S(i), D(j), "0" if f0 else AC0))
+            f0 = False
+            out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC1, A0(i), T(j), "0" if f1 else AC1))
+            f1 = False
+        for i in range(max(0, k - L + 1), min(k - 1, L - 1) + 1):
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC0, R0(i), P(k - i), AC0))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC1, R1(i), P(k - i), AC1))
+        if k < L:
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R0(k), LO0, INV))
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R1(k), LO1, INV))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R0(k), R0(k)))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R1(k), R1(k)))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC0, R0(k), P(0), AC0))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC1, R1(k), P(0), AC1))
+        else:
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R0(k - L), LO0))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R1(k - L), LO1))
+        out.append("v_ashrrev_i64 %s, 28, %s" % (AC0, AC0))
+        out.append("v_ashrrev_i64 %s, 28, %s" % (AC1, AC1))
+    out.append("v_mov_b32 %s, %s" % (R0(L - 1), LO0))
+    out.append("v_mov_b32 %s, %s" % (R1(L - 1), LO1))
+    out.append("s_setpc_b64 s[34:35]")
+    return out
+
+
+def gen_fp2sqr_call(L):
+    NLT = "\\n\\t"
+    sym = "gs_fp2sqr28_sub_%d" % L
+    o = ['extern "C" __device__ void %s();' % sym]
+    body = ["s_branch .Lgs_skipq%d_%%=" % L, ".p2align 8", ".globl %s" % sym, ".type %s,@function" % sym, sym + ":"]
+    body += sub_body_fp2sqr(L) + [".Lgs_skipq%d_%%=:" % L]
+    o.append('extern "C" __device__ __attribute__((used, noinline)) void gs_fp2sqr28_sub_holder_%d() {' % L)
+    o.append('  asm volatile("%s" ::: "memory");' % NLT.join(body))
+    o.append("}")
+    outs = ", ".join('"={v%d}"(r0[%d])' % (2 * L + i, i) for i in range(L)) + ", " + \
+        ", ".join('"={v%d}"(r1[%d])' % (3 * L + i, i) for i in range(L))
+    ins = []
+    for base, nm in ((0, "a0"), (L, "a1")):
+        ins += ['"{v%d}"(%s[%d])' % (base + i, nm, i) for i in range(L)]
+    ins += ['"{s%d}"(C::P28[%d])' % (40 + i, i) for i in range(L)] + ['"{s%d}"(C::P28_INV)' % (40 + L)]
+    nin = 2 * L + L + 1
+    ins.append('"s"((uint64_t)(uintptr_t)&%s)' % sym)
+    clob = ['"v%d"' % (4 * L + i) for i in range(3 * L + 4)] + ['"vcc"', '"s34"', '"s35"']
+    o.append("template <class C> __device__ __forceinline__ void fp2sqr28_call_%d(int32_t (&r0)[%d], int32_t (&r1)[%d], "
+             "const int32_t (&a0)[%d], const int32_t (&a1)[%d]) {" % (L, L, L, L, L))
+    o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (2 * L + nin))
+    o.append("      : %s" % outs)
+    o.append("      : %s" % ", ".join(ins))
+    o.append("      : %s);" % ", ".join(clob))
+    o.append("}")
+    return "\n".join(o), len(sub_body_fp2sqr(L))
+
+
 def gen_calls(L):
     NL = "\\n\\t"  # the two escapes as they must appear inside the C string literal
     o = []
@@ -277,6 +354,9 @@ def main():
         o.append(gen_calls(L))
         src, cnt = gen_fp2_call(L)
         o.append("// Fp2 product (schoolbook, lazy reduction), L = %d: %d instructions" % (L, cnt))
+        o.append(src)
+        src, cnt = gen_fp2sqr_call(L)
+        o.append("// Fp2 squaring, L = %d: %d instructions" % (L, cnt))
         o.append(src)
     o.append("#endif")
     with open(os.path.join(here, "gs_mul28_asm.h"), "w") as f:

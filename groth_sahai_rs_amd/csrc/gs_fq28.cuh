@@ -391,6 +391,89 @@ template <class C> GS_HD void fp2mul28(Fq28<C>& r0, Fq28<C>& r1, const Fq28<C>& 
 #endif
 }
 
+// Fp2 squaring kernel: c0 = (a0 + a1)(a0 - a1), c1 = (2 a0) a1 with one reduction each; inputs with A <= 2
+template <class C, class T> GS_HD void fp2sqr28_generic(T* r0, T* r1, const T* a0, const T* a1) {
+  constexpr int L = C::L;
+  uint32_t m0[L], m1[L];
+  int64_t s[L], d[L], t[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    s[i] = (int64_t)a0[i] + a1[i];
+    d[i] = (int64_t)a0[i] - a1[i];
+    t[i] = (int64_t)a1[i] * 2;
+#if defined(GS_FQ28_CHECK)
+    const int64_t lim = (int64_t)1 << 31;
+    if (s[i] >= lim || s[i] < -lim || d[i] >= lim || d[i] < -lim || t[i] >= lim || t[i] < -lim) {
+      fprintf(stderr, "Fp2 squaring: operand sums leave the 32-bit range\n");
+      abort();
+    }
+#endif
+  }
+#if defined(GS_FQ28_CHECK)
+  __int128 acc0 = 0, acc1 = 0;
+#else
+  int64_t acc0 = 0, acc1 = 0;
+#endif
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (j < 0 || j >= L) continue;
+      acc0 += s[i] * d[j];
+      acc1 += (int64_t)a0[i] * t[j];
+      if (j >= 1 && i < k) {
+        acc0 += (int64_t)(int32_t)m0[i] * C::P28[j];
+        acc1 += (int64_t)(int32_t)m1[i] * C::P28[j];
+      }
+    }
+#if defined(GS_FQ28_CHECK)
+    {
+      const __int128 lim = (__int128)1 << 63;
+      if (acc0 >= lim || acc0 < -lim || acc1 >= lim || acc1 < -lim) {
+        fprintf(stderr, "Fp2 squaring: column accumulator leaves the signed 64-bit range (A > 2)\n");
+        abort();
+      }
+    }
+#endif
+    if (k < L) {
+      m0[k] = ((((uint32_t)acc0) & (uint32_t)M28) * C::P28_INV) & (uint32_t)M28;
+      m1[k] = ((((uint32_t)acc1) & (uint32_t)M28) * C::P28_INV) & (uint32_t)M28;
+      acc0 += (int64_t)(int32_t)m0[k] * C::P28[0];
+      acc1 += (int64_t)(int32_t)m1[k] * C::P28[0];
+    } else {
+      r0[k - L] = (T)(((uint32_t)acc0) & (uint32_t)M28);
+      r1[k - L] = (T)(((uint32_t)acc1) & (uint32_t)M28);
+    }
+    acc0 >>= 28;
+    acc1 >>= 28;
+  }
+  r0[L - 1] = (T)acc0;
+  r1[L - 1] = (T)acc1;
+}
+template <class C> GS_HD void fp2sqr28(Fq28<C>& r0, Fq28<C>& r1, const Fq28<C>& a0, const Fq28<C>& a1) {
+#if defined(GS_FQ28_CHECK)
+  fq28_mul_counter().fetch_add(2, std::memory_order_relaxed);  // counted as the two products it replaces
+  for (const Fq28<C>* x : {&a0, &a1}) {
+    int64_t t = x->v[C::L - 1] < 0 ? -(int64_t)x->v[C::L - 1] : x->v[C::L - 1];
+    if (t >= (1 << 26)) {
+      fprintf(stderr, "Fp2 squaring: operand value out of range (top limb %lld)\n", (long long)t);
+      abort();
+    }
+  }
+  fp2sqr28_generic<C, limb_t>(r0.v, r1.v, a0.v, a1.v);
+  GS_CHK_LIMBS(r0)
+  GS_CHK_LIMBS(r1)
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM) && !defined(GS_NO_ASM_CALL)
+  if constexpr (C::L == 14)
+    fp2sqr28_call_14<C>(r0.v, r1.v, a0.v, a1.v);
+  else
+    fp2sqr28_call_10<C>(r0.v, r1.v, a0.v, a1.v);
+#else
+  fp2sqr28_generic<C, int32_t>(r0.v, r1.v, a0.v, a1.v);
+#endif
+}
+
 // ---- tests modulo p --------------------------------------------------------------
 // robust a == 0 (mod p) for any lazily reduced a within the mul contract: one
 // multiplication by 1 brings the value into (-p/2, 3p/2) with unique limbs, where

@@ -81,6 +81,15 @@ template <class C> GS_HD Fp2<C> mul_l2(const Fp2<C>& a, const Fp2<C>& b) {
   return {sub(v0, v1), norm(sub(sub(s, v0), v1))};
 }
 #endif
+#if !defined(GS_FP2_KARATSUBA)
+// one multiplier kernel (fp2sqr28): inputs with A <= 2, both outputs N
+template <class C> GS_HD Fp2<C> sqr(const Fp2<C>& a) {
+  Fp2<C> r;
+  fp2sqr28<C>(r.c0, r.c1, a.c0, a.c1);
+  return r;
+}
+template <class C> GS_HD Fp2<C> sqr_l2(const Fp2<C>& a) { return sqr(a); }
+#else
 template <class C> GS_HD Fp2<C> sqr(const Fp2<C>& a) {
   Fq<C> t = mul(a.c0, a.c1);
   return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), norm(dbl(t))};
@@ -89,6 +98,7 @@ template <class C> GS_HD Fp2<C> sqr_l2(const Fp2<C>& a) {
   Fq<C> t = mul(a.c0, a.c1);
   return {mul(add(a.c0, a.c1), norm(sub(a.c0, a.c1))), norm(dbl(t))};
 }
+#endif
 template <class C> GS_HD Fp2<C> mul_fp(const Fp2<C>& a, const Fq<C>& k) { return {mul(a.c0, k), mul(a.c1, k)}; }
 // lazy: A_out = (XI_A + 1) * A_in
 template <class C> GS_HD Fp2<C> mul_xi(const Fp2<C>& a) {
