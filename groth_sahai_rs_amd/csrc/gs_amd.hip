@@ -93,6 +93,7 @@ struct gs_ctx {
   size_t simd_slots = 1024;
   // planner overrides (gs_set_option; 0 / -1 = planned per batch)
   int var_tm = 0;
+  int var_mo = 0, var_w = 0;  // outputs per Straus lane (1, 2, 4) and its window width (4, 5); 0 = planned
   int miller_ch = 0, miller_twin = -1;
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
   bool line_tables = true;  // pairs whose G2 argument is a CRS element read precomputed Miller lines
@@ -239,6 +240,7 @@ static std::vector<double> miller_budgets(const gs_ctx* c, bool twin) {
   return out;
 }
 
+static const size_t VAR_WS_LANES = (size_t)1 << 19;  // k_var_multi lanes per launch (G2, 8 terms: 14 KB of table each)
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
 template <class K, class... Args>
 static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, Args... args) {
@@ -340,6 +342,8 @@ template <class T> static int upload(gs_ctx* c, const char* name, const std::vec
 struct SidePlan {
   std::vector<GrpTask> grp;  // when tm > 1: lanes of k_var_multi (each sums <= tm consecutive var tasks)
   int tm = 1;
+  int mo = 1, w = 4;  // outputs per lane after share_tables(), window width
+  bool shared_done = false;
   std::vector<VarTask> var;
   std::vector<FixTask> fix;
   std::vector<RedTask> red;
@@ -389,10 +393,11 @@ static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& 
   for (size_t k = 0; k < ng; k++) {  // balanced groups: sizes differ by <= 1
     size_t n = base + (k < rem ? 1 : 0);
     GrpTask g;
-    g.first = (uint32_t)sp.var.size();
+    memset(&g, 0, sizeof g);
+    g.first[0] = (uint32_t)sp.var.size();
     g.nt = (uint32_t)n;
-    g.slot = (uint32_t)slot;
-    g.pad = 0;
+    g.no = 1;
+    g.slot[0] = (uint32_t)slot;
     for (size_t i = 0; i < n; i++) {
       VarTask v = terms[s0 + i];
       v.slot = (uint32_t)slot;
@@ -427,6 +432,86 @@ static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
     }
   }
   return best_tm;
+}
+
+// Lane cost of the joint MSM in Fq multiplications: one table build of `nt` bases (2^(w-1) entries each: doublings,
+// mixed additions, 7 multiplications per entry for the common denominator) + `no` main loops (w doublings per window,
+// one mixed addition per non-zero digit, the endomorphism on the looked-up entry).
+static double straus_lane_cost(bool g2, bool bn, int nt, int no, int w) {
+  const double madd = g2 ? 29.0 : 11.0, dbl = g2 ? 16.0 : 8.0, gz = g2 ? 21.0 : 7.0, endo = g2 ? 4.0 : 0.5;
+  const int ns = g2 ? 4 : 2, nl = g2 ? (bn ? 3 : 2) : (bn ? 5 : 4), nd = (32 * nl + w - 1) / w + 1, ne = 1 << (w - 1);
+  double build = nt * (ne / 2 * dbl + (ne / 2 - 1) * madd + ne * gz);
+  double run = (nd - 1) * w * dbl + (double)nt * ns * (nd - 0.5) * (1.0 - 1.0 / (2 * ne)) * (madd + endo);
+  return build + no * run;
+}
+// Groups with the same bases (same arrays, indices and signs in the same order) become ONE lane of up to `mo` outputs
+// that builds its tables once: the proof elements of a side share their constants and variables, the columns of
+// Gamma^T c share the commitments.  Picks (mo, w) by the cost model of pick_tm unless overridden.
+static void share_tables(const gs_ctx* c, size_t N, SidePlan& sp, bool g2) {
+  if (sp.shared_done) return;
+  sp.shared_done = true;
+  sp.mo = 1;
+  sp.w = 4;
+  if (sp.tm <= 1 || sp.grp.empty()) return;
+  auto sig = [&](const GrpTask& g) {
+    std::string k((const char*)&g.nt, sizeof g.nt);
+    for (uint32_t i = 0; i < g.nt; i++) {
+      const VarTask& v = sp.var[g.first[0] + i];
+      k.append((const char*)&v.p_idx, sizeof v.p_idx);
+      k.push_back((char)v.p_arr);
+      k.push_back((char)v.neg);
+    }
+    return k;
+  };
+  std::map<std::string, std::vector<size_t>> fam;  // signature -> groups, in plan order
+  std::vector<std::string> order;
+  int ntmax = 1;
+  for (size_t i = 0; i < sp.grp.size(); i++) {
+    std::string k = sig(sp.grp[i]);
+    if (!fam.count(k)) order.push_back(k);
+    fam[k].push_back(i);
+    ntmax = std::max(ntmax, (int)sp.grp[i].nt);
+  }
+  size_t share = 1;
+  for (auto& f : fam) share = std::max(share, f.second.size());
+  int best_mo = 1, best_w = 4;
+  double best = -1;
+  for (int mo : {1, 2, 4}) {
+    if (c->var_mo > 0 && mo != c->var_mo) continue;
+    if (c->var_mo <= 0 && (size_t)mo > share) continue;
+    size_t lanes = 0;
+    for (auto& f : fam) lanes += (f.second.size() + mo - 1) / mo;
+    for (int w : {4, 5}) {
+      if (c->var_w > 0 && w != c->var_w) continue;
+      double waves = (double)N * lanes / 64.0;
+      double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
+      if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);
+      int eff_mo = (int)std::min((size_t)mo, share);
+      double cost = rounds * straus_lane_cost(g2, c->curve == 1, ntmax, eff_mo, w);
+      if (best < 0 || cost < best) {
+        best = cost;
+        best_mo = mo;
+        best_w = w;
+      }
+    }
+  }
+  sp.mo = best_mo;
+  sp.w = best_w;
+  if (best_mo == 1) return;
+  std::vector<GrpTask> merged;
+  for (const std::string& k : order) {
+    const std::vector<size_t>& f = fam[k];
+    for (size_t b = 0; b < f.size(); b += best_mo) {
+      GrpTask g = sp.grp[f[b]];
+      g.no = (uint32_t)std::min((size_t)best_mo, f.size() - b);
+      for (uint32_t o = 1; o < g.no; o++) {
+        g.first[o] = sp.grp[f[b + o]].first[0];
+        g.slot[o] = sp.grp[f[b + o]].slot[0];
+      }
+      merged.push_back(g);
+    }
+  }
+  sp.grp.swap(merged);
 }
 
 // Build the plan of one side.
@@ -525,10 +610,11 @@ template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLau
   return launch(c, r.name.c_str(), k_red<C, F>, N * r.nred, 64, N * r.nred, (int)r.nred, dred, part, nslots, r.outs);
 }
 template <class C, class F>
-static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
+static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
                     int pool_n, const Aff<F>* tab, const OutTab& outs, hipStream_t vstream = nullptr,
                     hipEvent_t vev0 = nullptr, hipEvent_t vev1 = nullptr, RedLaunch* defer = nullptr) {
   std::string t(tag);
+  share_tables(c, N, sp, std::is_same<F, Fp2<C>>::value);
   const VarTask* dvar;
   const FixTask* dfix;
   RC(upload(c, (t + ".var").c_str(), sp.var, &dvar));
@@ -558,12 +644,23 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, const SidePlan& sp, co
     RC(upload(c, (t + ".grp").c_str(), sp.grp, &dgrp));
     size_t tot = N * sp.grp.size();
     c->work_hint = N * sp.var.size();  // terms
-    if (sp.tm <= 4)
-      RC(launch(c, (std::string("k_var_multi4") + tag).c_str(), k_var_multi<C, F, 4>, tot, 64, tot, (int)sp.grp.size(),
-                dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
-    else
-      RC(launch(c, (std::string("k_var_multi8") + tag).c_str(), k_var_multi<C, F, 8>, tot, 64, tot, (int)sp.grp.size(),
-                dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
+    // the lanes' Straus tables: lane-contiguous global workspace (see jac_msm_straus_at), at most VAR_WS_LANES lanes
+    // of it; a larger batch goes in several launches over the same workspace
+    const int tmax = sp.tm <= 4 ? 4 : 8;
+    const size_t chunk = std::min(tot, VAR_WS_LANES);
+    void* tabws;
+    RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * sizeof(Aff<F>), &tabws));
+    // kernel name: k_var_multi<TMAX>[w5][x<outputs per lane>]
+    std::string kn = std::string("k_var_multi") + (tmax == 4 ? "4" : "8") + (sp.w == 5 ? "w5" : "") +
+                     (sp.mo > 1 ? "x" + std::to_string(sp.mo) : "") + tag;
+    auto kern = tmax == 4 ? (sp.w == 5 ? k_var_multi<C, F, 4, 5> : k_var_multi<C, F, 4, 4>)
+                          : (sp.w == 5 ? k_var_multi<C, F, 8, 5> : k_var_multi<C, F, 8, 4>);
+    for (size_t g0 = 0; g0 < tot; g0 += chunk) {
+      size_t n = std::min(chunk, tot - g0);
+      c->work_hint = (uint64_t)((double)N * sp.var.size() * ((double)n / (double)tot));  // terms
+      RC(launch(c, kn.c_str(), kern, n, 64, tot, (int)sp.grp.size(), dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part,
+                sp.nslots, g0, (Aff<F>*)tabws));
+    }
   }
   if (fork) {  // join before the reduction
     hipEventRecord(vev1, vstream);
@@ -1575,6 +1672,8 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
   if (const char* e = getenv("GS_MILLER_TWIN")) c->miller_twin = atoi(e);
   if (const char* e = getenv("GS_LINE_TABLES")) c->line_tables = atoi(e) != 0;
   if (const char* e = getenv("GS_VAR_TM")) c->var_tm = atoi(e);
+  if (const char* e = getenv("GS_VAR_MO")) c->var_mo = atoi(e);
+  if (const char* e = getenv("GS_VAR_W")) c->var_w = atoi(e);
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return GS_ERR_DEVICE;
@@ -1626,6 +1725,12 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
   } else if (k == "var_tm") {
     if (value < 0 || value > 8) return fail(c, GS_ERR_ARG, "var_tm: 0 (planned) .. 8");
     c->var_tm = value;
+  } else if (k == "var_mo") {
+    if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_ARG, "var_mo: 0 (planned), 1, 2, 4");
+    c->var_mo = value;
+  } else if (k == "var_w") {
+    if (value != 0 && value != 4 && value != 5) return fail(c, GS_ERR_ARG, "var_w: 0 (planned), 4, 5");
+    c->var_w = value;
   } else if (k == "coop_fe") {
     if (value < 0 || value > 2) return fail(c, GS_ERR_ARG, "coop_fe: 0 never, 1 planned, 2 always");
     c->coop_fe = value;

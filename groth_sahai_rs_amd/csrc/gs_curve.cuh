@@ -225,7 +225,8 @@ template <class M> GS_HD void recode_w4(int8_t* dg, int nd, const Fe<M>& k) {
 }
 
 // r = k * P  (k canonical scalar in Fr's limb type M)
-template <class F, class M> GS_HD_NOINLINE void jac_smul(Jac<F>& r, const Aff<F>& p, const Fe<M>& k) {
+template <class F, class M> GS_HD_NOINLINE void jac_smul(Jac<F>& rout, const Aff<F>& p, const Fe<M>& k) {
+  Jac<F> r;  // local running sum (see jac_msm_straus_at)
   constexpr int ND = (M::BITS + 3) / 4 + 1;  // one spare digit for the signed carry
   Jac<F> tab[8];
   Aff<F> at[8];
@@ -249,6 +250,7 @@ template <class F, class M> GS_HD_NOINLINE void jac_smul(Jac<F>& r, const Aff<F>
     }
   }
   r.z = mul(r.z, zback);
+  rout = r;
 }
 
 // ---------------------------------------------------------------------------
@@ -299,6 +301,40 @@ template <int NL> GS_HD void recode_w4_limbs(int8_t* dg, const uint32_t* k) {
       dg[i] = (int8_t)v;
       carry = 0;
     }
+  }
+}
+
+// signed width-W digits (in [-2^(W-1), 2^(W-1))) of an NL-limb value; (32 NL + W - 1) / W + 1 of them
+template <int NL, int W> GS_HD void recode_w_limbs(int8_t* dg, const uint32_t* k) {
+  constexpr int ND = (32 * NL + W - 1) / W + 1;
+  uint32_t carry = 0;
+  for (int i = 0; i < ND; i++) {
+    int bit = i * W;
+    uint32_t v = 0;
+    if (bit < 32 * NL) {
+      v = k[bit >> 5] >> (bit & 31);
+      if ((bit & 31) + W > 32 && (bit >> 5) + 1 < NL) v |= k[(bit >> 5) + 1] << (32 - (bit & 31));
+      v &= (1u << W) - 1u;
+    }
+    v += carry;
+    if (v >= (1u << (W - 1))) {
+      dg[i] = (int8_t)((int)v - (1 << W));
+      carry = 1;
+    } else {
+      dg[i] = (int8_t)v;
+      carry = 0;
+    }
+  }
+}
+// tab[i] = (i + 1) P, i = 0 .. NE-1 (k even: 2 (k/2)P; k odd: (k-1)P + P)
+template <class F> GS_HD_NOINLINE void smul_build_table_n(Jac<F>* tab, const Aff<F>& p, int ne) {
+  jac_from_aff(tab[0], p);
+#pragma unroll 1
+  for (int k = 2; k <= ne; k++) {
+    if (k & 1)
+      jac_madd(tab[k - 1], tab[k - 2], p);
+    else
+      jac_dbl(tab[k - 1], tab[k / 2 - 1]);
   }
 }
 
@@ -364,7 +400,8 @@ GS_HD void endo_lattice(uint32_t (*mag)[NL], uint8_t* sgn, const uint32_t* k, co
   }
 }
 
-template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fq<C>>& r, const Aff<Fq<C>>& p, const Fr<C>& k) {
+template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fq<C>>& rout, const Aff<Fq<C>>& p, const Fr<C>& k) {
+  Jac<Fq<C>> r;
   uint32_t kk[8], q[8], k1[4], k2[4], lam[4];
   for (int i = 0; i < 8; i++) kk[i] = k.v[i];
   for (int i = 0; i < 4; i++) lam[i] = C::LAMBDA[i];
@@ -401,6 +438,7 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fq<C>>& r, const Aff<Fq
     }
   }
   r.z = mul(r.z, zback);
+  rout = r;
 }
 
 template <class C> GS_HD Fp2<C> fp2_const28(const int32_t (*c)[C::L]) {
@@ -444,7 +482,8 @@ template <class C> GS_HD void endo_apply(Aff<Fp2<C>>& t, int s) {
     t.y = mul(conj(t.y), fp2_const28<C>(C::PSI3_Y_28));
   }
 }
-template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fp2<C>>& r, const Aff<Fp2<C>>& p, const Fr<C>& k) {
+template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fp2<C>>& rout, const Aff<Fp2<C>>& p, const Fr<C>& k) {
+  Jac<Fp2<C>> r;
   // base-|x| digits of k
   uint32_t n[8], q[8], xa[2], d[4][2];
   for (int i = 0; i < 8; i++) n[i] = k.v[i];
@@ -480,10 +519,15 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fp2<C>>& r, const Aff<F
     }
   }
   r.z = mul(r.z, zback);
+  rout = r;
 }
 
 template <class C, class F, int TMAX>
-GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks, int nt);
+GS_HD void jac_msm_straus_at(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks, int nt, Aff<F>* at);
+template <class C, class F, int TMAX> GS_HD void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks, int nt) {
+  Aff<F> at[TMAX * 8];
+  jac_msm_straus_at<C, F, TMAX>(r, ps, ks, nt, at);
+}
 // dispatch: endomorphism path where the curve has one (BN curves: the one-term case of the joint routine, whose
 // digit streams come from the lattice decomposition)
 template <class C, class F> GS_HD void jac_smul_any(Jac<F>& r, const Aff<F>& p, const Fr<C>& k) {
@@ -508,36 +552,40 @@ template <class C, class F> GS_HD void jac_smul_any(Jac<F>& r, const Aff<F>& p, 
 template <class C, class F> struct EndoShape;
 template <class C> struct EndoShape<C, Fq<C>> {
   static constexpr int NS = 2, NL = C::IS_BN ? 5 : 4, ND = 8 * NL + 1;
+  static constexpr int nd(int w) { return (32 * NL + w - 1) / w + 1; }
 };
 template <class C> struct EndoShape<C, Fp2<C>> {
   static constexpr int NS = 4, NL = C::IS_BN ? 3 : 2, ND = 8 * NL + 1;
+  static constexpr int nd(int w) { return (32 * NL + w - 1) / w + 1; }
 };
-template <class C> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, const Fr<C>& k, const Jac<Fq<C>>*) {
+template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, const Fr<C>& k, const Jac<Fq<C>>*) {
   typedef EndoShape<C, Fq<C>> E;
+  constexpr int ND = E::nd(W);
   uint32_t kk[8];
   for (int i = 0; i < 8; i++) kk[i] = k.v[i];
   if constexpr (C::IS_BN) {
     uint32_t mag[2][E::NL];
     endo_lattice<2, 5, 4, E::NL>(mag, sgn, kk, C::GLV1_G, C::GLV1_GS, C::GLV1_B, C::GLV1_BS);
-    for (int s = 0; s < 2; s++) recode_w4_limbs<E::NL>(dg + E::ND * s, mag[s]);
+    for (int s = 0; s < 2; s++) recode_w_limbs<E::NL, W>(dg + ND * s, mag[s]);
   } else {
     uint32_t q[8], k1[4], k2[4], lam[4];
     for (int i = 0; i < 4; i++) lam[i] = C::LAMBDA[i];
     limb_divmod<8, 4>(q, k1, kk, lam);
     for (int i = 0; i < 4; i++) k2[i] = q[i];
-    recode_w4_limbs<4>(dg, k1);
-    recode_w4_limbs<4>(dg + E::ND, k2);
+    recode_w_limbs<4, W>(dg, k1);
+    recode_w_limbs<4, W>(dg + ND, k2);
     sgn[0] = sgn[1] = 0;
   }
 }
-template <class C> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, const Fr<C>& k, const Jac<Fp2<C>>*) {
+template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, const Fr<C>& k, const Jac<Fp2<C>>*) {
   typedef EndoShape<C, Fp2<C>> E;
+  constexpr int ND = E::nd(W);
   uint32_t n[8];
   for (int i = 0; i < 8; i++) n[i] = k.v[i];
   if constexpr (C::IS_BN) {
     uint32_t mag[4][E::NL];
     endo_lattice<4, 7, 2, E::NL>(mag, sgn, n, C::GLS2_G, C::GLS2_GS, C::GLS2_B, C::GLS2_BS);
-    for (int s = 0; s < 4; s++) recode_w4_limbs<E::NL>(dg + E::ND * s, mag[s]);
+    for (int s = 0; s < 4; s++) recode_w_limbs<E::NL, W>(dg + ND * s, mag[s]);
   } else {
     uint32_t q[8], xa[2], d[4][2];
     xa[0] = C::XABS_LIMBS[0];
@@ -549,59 +597,62 @@ template <class C> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, const Fr<C>&
     d[3][0] = n[0];
     d[3][1] = n[1];
     for (int j = 0; j < 4; j++) {
-      recode_w4_limbs<2>(dg + E::ND * j, d[j]);
+      recode_w_limbs<2, W>(dg + ND * j, d[j]);
       sgn[j] = (uint8_t)(j & 1);  // x < 0: psi acts as -|x|
     }
   }
 }
 
-template <class C, class F, int TMAX>
-GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks, int nt) {
+// Tables and main loop are separate routines so that SEVERAL outputs over the same bases (the two proof elements of a
+// side, the n columns of Gamma^T c in the verifier) share one table build: jac_straus_build once, jac_straus_run per
+// output.  W = window width (signed digits, NE = 2^(W-1) entries per base): 4, or 5 when the build is shared.
+// `at` = room for NE * TMAX table entries.  The main loop indexes it with the lane's own digit, so it must NOT live in
+// the kernel's private frame: scratch is interleaved dword by dword across the 64 lanes of a wave, and 64 lanes reading
+// 8 different entries pull 8 rows of 256 bytes for every 256 bytes they use.  The kernels pass a lane-contiguous
+// global workspace instead (one entry = consecutive bytes of one lane).
+template <class C, class F, int TMAX, int W>
+GS_HD_NOINLINE void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int nt) {
+  constexpr int NE = 1 << (W - 1);
+  Jac<F> tab[TMAX * NE];
+  for (int t = 0; t < nt; t++) smul_build_table_n(tab + t * NE, ps[t], NE);
+  table_global_z<C>(at, tab, NE * nt, zback);  // ONE isomorphic curve for all the terms' tables
+}
+template <class C, class F, int TMAX, int W>
+GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F>* at, const F& zback) {
+  constexpr int NE = 1 << (W - 1);
+  Jac<F> r;  // the running sum stays a local (registers): a reference parameter is memory at every step
   if constexpr (C::HAS_ENDO) {
     typedef EndoShape<C, F> E;
-    Jac<F> tab[TMAX][8];
-    Aff<F> at[TMAX][8];
-    F zback;
-    int8_t dg[TMAX][E::NS * E::ND];
+    constexpr int ND = E::nd(W);
+    int8_t dg[TMAX][E::NS * ND];
     uint8_t sg[TMAX][E::NS];
-    for (int t = 0; t < nt; t++) {
-      smul_build_table(tab[t], ps[t]);
-      endo_digits<C>(dg[t], sg[t], ks[t], (const Jac<F>*)nullptr);
-    }
-    table_global_z<C>(&at[0][0], &tab[0][0], 8 * nt, zback);  // ONE isomorphic curve for all the terms' tables
+    for (int t = 0; t < nt; t++) endo_digits<C, W>(dg[t], sg[t], ks[t], (const Jac<F>*)nullptr);
     jac_set_inf(r);
     int top = 0;  // highest window with a non-zero digit: short scalars skip their leading doublings
     for (int t = 0; t < nt; t++)
       for (int s = 0; s < E::NS; s++)
-        for (int i = E::ND - 1; i > top; i--)
-          if (dg[t][s * E::ND + i] != 0) top = i;
+        for (int i = ND - 1; i > top; i--)
+          if (dg[t][s * ND + i] != 0) top = i;
     for (int i = top; i >= 0; i--) {
       if (i != top) {
 #pragma unroll 1
-        for (int d4 = 0; d4 < 4; d4++) jac_dbl(r, r);
+        for (int d4 = 0; d4 < W; d4++) jac_dbl(r, r);
       }
       for (int t = 0; t < nt; t++)
         for (int s = 0; s < E::NS; s++) {
-          int a = dg[t][s * E::ND + i];
+          int a = dg[t][s * ND + i];
           if (a == 0) continue;
-          Aff<F> e = at[t][(a < 0 ? -a : a) - 1];
+          Aff<F> e = at[t * NE + (a < 0 ? -a : a) - 1];
           endo_apply<C>(e, s);
           if ((a < 0) != (sg[t][s] != 0)) e.y = neg(e.y);
           jac_madd(r, r, e);
         }
     }
-    r.z = mul(r.z, zback);
   } else {
+    static_assert(C::HAS_ENDO || W == 4, "plain curves: width 4 only");
     constexpr int ND = (FrM<C>::BITS + 3) / 4 + 1;
-    Jac<F> tab[TMAX][8];
-    Aff<F> at[TMAX][8];
-    F zback;
     int8_t dg[TMAX][ND];
-    for (int t = 0; t < nt; t++) {
-      smul_build_table(tab[t], ps[t]);
-      recode_w4<FrM<C>>(dg[t], ND, ks[t]);
-    }
-    table_global_z<C>(&at[0][0], &tab[0][0], 8 * nt, zback);
+    for (int t = 0; t < nt; t++) recode_w4<FrM<C>>(dg[t], ND, ks[t]);
     jac_set_inf(r);
     int top = 0;
     for (int t = 0; t < nt; t++)
@@ -615,13 +666,20 @@ GS_HD_NOINLINE void jac_msm_straus(Jac<F>& r, const Aff<F>* ps, const Fr<C>* ks,
       for (int t = 0; t < nt; t++) {
         int a = dg[t][i];
         if (a == 0) continue;
-        Aff<F> e = at[t][(a < 0 ? -a : a) - 1];
+        Aff<F> e = at[t * NE + (a < 0 ? -a : a) - 1];
         if (a < 0) e.y = neg(e.y);
         jac_madd(r, r, e);
       }
     }
-    r.z = mul(r.z, zback);
   }
+  r.z = mul(r.z, zback);
+  rout = r;
+}
+template <class C, class F, int TMAX>
+GS_HD void jac_msm_straus_at(Jac<F>& rout, const Aff<F>* ps, const Fr<C>* ks, int nt, Aff<F>* at) {
+  F zback;
+  jac_straus_build<C, F, TMAX, 4>(at, zback, ps, nt);
+  jac_straus_run<C, F, TMAX, 4>(rout, ks, nt, at, zback);
 }
 
 }  // namespace gs

@@ -36,8 +36,10 @@ struct VarTask {
   uint32_t s_idx, p_idx, slot;  // 32-bit: large-arity equations (m, n ~ 334, benches/bench.rs:451-498) have > 2^16 scalars
   uint8_t p_arr, neg, pad0, pad1;  // neg: use -P
 };
-struct GrpTask {  // nt consecutive VarTasks summed by one lane (Straus) into one slot
-  uint32_t first, nt, slot, pad;
+constexpr int GRP_OUT = 4;  // outputs one Straus lane can serve from one table build
+struct GrpTask {  // one lane of k_var_multi: `no` outputs over the SAME nt bases (in the same order, same signs);
+  uint32_t nt, no;             // output o sums VarTasks first[o] .. first[o] + nt - 1 into slot[o]
+  uint32_t first[GRP_OUT], slot[GRP_OUT];
 };
 struct FixTask {
   uint32_t s0, s1, a_idx, slot;
@@ -458,26 +460,35 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, con
   part[e * nslots + t.slot] = J;
 }
 
-// joint MSM: one lane = one GrpTask (<= TMAX terms sharing a doubling chain)
-template <class C, class F, int TMAX>
+// joint MSM: one lane = one GrpTask (<= TMAX bases sharing a doubling chain; the lane's table build serves all of the
+// group's outputs, which run one after the other)
+template <class C, class F, int TMAX, int W>
 __global__ void __launch_bounds__(64, GS_WPE) k_var_multi(size_t total, int ngrp, const GrpTask* grps, const VarTask* tasks,
                                                   ArrTab arrs, const Fr<C>* pool, int pool_n, Jac<F>* part,
-                                                  int nslots) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                  int nslots, size_t g0, Aff<F>* tabws) {
+  size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // lane within this launch = its slot in `tabws`
+  size_t g = g0 + w;
   if (g >= total) return;
   size_t e = g / ngrp;
   GrpTask gt = grps[g % ngrp];
-  Aff<F> P[TMAX];
-  Fr<C> k[TMAX];
-  for (uint32_t i = 0; i < gt.nt; i++) {
-    VarTask t = tasks[gt.first + i];
-    k[i] = pool[e * pool_n + t.s_idx];
-    aff_load<C>(P[i], arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
-    if (t.neg) P[i].y = neg(P[i].y);
+  Aff<F>* at = tabws + w * (size_t)(TMAX << (W - 1));
+  F zback;
+  {
+    Aff<F> P[TMAX];
+    for (uint32_t i = 0; i < gt.nt; i++) {
+      VarTask t = tasks[gt.first[0] + i];
+      aff_load<C>(P[i], arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
+      if (t.neg) P[i].y = neg(P[i].y);
+    }
+    jac_straus_build<C, F, TMAX, W>(at, zback, P, (int)gt.nt);
   }
-  Jac<F> J;
-  jac_msm_straus<C, F, TMAX>(J, P, k, (int)gt.nt);
-  part[e * nslots + gt.slot] = J;
+  for (uint32_t o = 0; o < gt.no; o++) {
+    Fr<C> k[TMAX];
+    for (uint32_t i = 0; i < gt.nt; i++) k[i] = pool[e * pool_n + tasks[gt.first[o] + i].s_idx];
+    Jac<F> J;
+    jac_straus_run<C, F, TMAX, W>(J, k, (int)gt.nt, at, zback);
+    part[e * nslots + gt.slot[o]] = J;
+  }
 }
 
 template <class C, class F>

@@ -163,8 +163,17 @@ template <class C> GS_HD_NOINLINE void miller_line_table(Line<C>* out, const Aff
 }
 
 template <class C>
-GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts,
+GS_HD_NOINLINE void multi_miller(Fp12<C>& fout, const Aff<Fq<C>>* ps, const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts,
                                  bool* live, const Line<C>* const* fixed = nullptr) {
+#if defined(GS_MILLER_LOCAL)
+  Fp12<C> f;
+  struct Out {
+    Fp12<C>&a, &o;
+    GS_HD ~Out() { o = a; }
+  } out_{f, fout};
+#else
+  Fp12<C>& f = fout;
+#endif
   f12_one(f);
   bool any = false;
   for (int k = 0; k < np; k++) {
@@ -237,9 +246,21 @@ GS_HD_NOINLINE void multi_miller(Fp12<C>& f, const Aff<Fq<C>>* ps, const Aff<Fp2
 // commitment-group element, data_structures.rs:484-502), so the tangent/chord
 // line of Q_k is computed once and evaluated at both: f0 *= l(P0_k), f1 *= l(P1_k).
 template <class C>
-GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0, Fp12<C>& f1, const Aff<Fq<C>>* p0, const Aff<Fq<C>>* p1,
+GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0out, Fp12<C>& f1out, const Aff<Fq<C>>* p0, const Aff<Fq<C>>* p1,
                                   const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts, uint8_t* live,
                                   const Line<C>* const* fixed = nullptr) {
+#if defined(GS_MILLER_LOCAL)
+  Fp12<C> f0, f1;  // locals: no aliasing with the pointer arguments, the allocator decides where they live
+  struct Out {
+    Fp12<C>&a, &b, &o0, &o1;
+    GS_HD ~Out() {
+      o0 = a;
+      o1 = b;
+    }
+  } out_{f0, f1, f0out, f1out};
+#else
+  Fp12<C>&f0 = f0out, &f1 = f1out;
+#endif
   f12_one(f0);
   f12_one(f1);
   bool any = false;
@@ -339,10 +360,14 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f
     // Granger-Scott squaring feeds 2*z back linearly: values double per step; a
     // full multiplication contracts them again, otherwise reduce every 3rd step
     if ((C::X_ABS >> i) & 1) {
-      f12_mul(acc, acc, f);
+      // `acc` must not have its address taken anywhere in this loop: it then lives in registers (AGPRs) from one
+      // squaring to the next instead of crossing memory twice per step (k_final 54.9 -> 44.5 ms at 2^16)
+      Fp12<C> t = acc;
+      f12_mul(t, t, f);
+      acc = t;
       since = 0;
     } else if (++since == 3) {
-      f12_vreduce(acc);
+      f12_vreduce_inl(acc);
       since = 0;
     }
   }

@@ -384,9 +384,11 @@ template <class C> GS_ML void f12_mul_by_lines2(Fp12<C>& f, const ELine<C>& u, c
 // easy part of the final exponentiation).
 template <class C> GS_HD void fp4_sqr(Fp2<C>& o0, Fp2<C>& o1, const Fp2<C>& a, const Fp2<C>& b) {
   // (a + b t)^2 with t^2 = xi:  o0 = a^2 + xi b^2, o1 = 2ab ; outputs N
+  // limb growth: a + b has A = 2 and meets a normalised factor (Fp2 product contract A_a A_b <= 4); the sum
+  // m - ab - xi ab stays within 3 x 2^28 per limb before its one carry round
   Fp2<C> ab = mul(a, b);
-  Fp2<C> m = mul(norm(add(a, b)), norm(add(a, mul_xi(b))));
-  o0 = norm(sub(sub(m, ab), norm(mul_xi(ab))));
+  Fp2<C> m = mul(add(a, b), norm(add(a, mul_xi(b))));
+  o0 = norm(sub(sub(m, ab), mul_xi(ab)));
   o1 = norm(dbl(ab));
 }
 template <class C> GS_HD void f12_cyclo_sqr_inl(Fp12<C>& r, const Fp12<C>& f) {
@@ -415,13 +417,17 @@ template <class C> GS_HD void f12_cyclo_sqr_inl(Fp12<C>& r, const Fp12<C>& f) {
 template <class C> GS_HD_NOINLINE void f12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& f) { f12_cyclo_sqr_inl(r, f); }
 
 // bring every coefficient's VALUE back to ~[-p, p] (see vreduce in gs_fq28.cuh)
-template <class C> GS_HD_NOINLINE void f12_vreduce(Fp12<C>& f) {
-  Fp2<C>* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
-  for (int i = 0; i < 6; i++) {
-    c[i]->c0 = vreduce(c[i]->c0);
-    c[i]->c1 = vreduce(c[i]->c1);
-  }
+template <class C> GS_HD void f12_vreduce_inl(Fp12<C>& f) {
+#define GS_VR2(x) x.c0 = vreduce(x.c0), x.c1 = vreduce(x.c1)
+  GS_VR2(f.c0.c0);
+  GS_VR2(f.c0.c1);
+  GS_VR2(f.c0.c2);
+  GS_VR2(f.c1.c0);
+  GS_VR2(f.c1.c1);
+  GS_VR2(f.c1.c2);
+#undef GS_VR2
 }
+template <class C> GS_HD_NOINLINE void f12_vreduce(Fp12<C>& f) { f12_vreduce_inl(f); }
 
 // ---- boundary I/O (include/gs_amd.h layout: saturated Montgomery limbs) -------
 template <class C> struct BFq {

@@ -6,6 +6,7 @@ proof verifies, every corrupted one is rejected, batched and exact verdicts agre
 `opts` are planner overrides (gs_set_option) that force a particular kernel shape; `expect` lists kernel names that
 must have run (checked through the library's HIP-event profile of a second, identical pass, whose outputs must equal
 the first's)."""
+import fnmatch
 import os
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -83,8 +84,8 @@ def run_batch(curve_id, cname, ty, N, m, n, sample, opts=None, expect=None, seed
         eng.sync()
         names = [p[0] for p in eng.prof_get()]
         eng.prof_enable(False)
-        for want in expect:
-            assert want in names, (want, names)
+        for want in expect:  # exact kernel name, or a pattern where the planner may pick a sub-variant
+            assert any(fnmatch.fnmatchcase(nm, want) for nm in names), (want, names)
         for a, t in ((xc, wl.xcoms), (yc, wl.ycoms), (pi, wl.pi), (th, wl.theta)):
             assert (t.cpu().numpy() == a).all()
         assert wl.ok.cpu().numpy().all()

@@ -1,7 +1,7 @@
 """Every kernel SHAPE the planner can pick is compared with the C oracle.
 
 The planner (csrc/gs_amd.hip: miller_cost, pick_tm, coop_fe) switches kernels with the batch size: twin-accumulator
-Miller lanes, 2..6 pairs per lane, Straus groups of 4 / 8 terms, one-lane or 3-lane final exponentiation, table-reading
+Miller lanes, 2..6 pairs per lane, Straus groups of 4 / 8 terms (one to four outputs per table build, 4- or 5-bit windows), one-lane or 3-lane final exponentiation, table-reading
 or stepping CRS pairs, side streams.  At the small N the oracle can follow, the planner alone would only ever choose
 the small-batch shapes; here every shape is FORCED through gs_set_option, all four equation types, both curves, every
 equation of the batch bit-exact (commitments, pi, theta) and verdict-exact against oracle/gs_ref.c, and the library's
@@ -15,12 +15,20 @@ pytestmark = pytest.mark.gpu
 
 # name -> options; chosen so that every value of every knob occurs with both values of its neighbours
 SHAPES = {
-    "twin6_straus8_lane": dict(miller_twin=1, miller_ch=6, var_tm=8, coop_fe=0, line_tables=1, overlap=0),
-    "twin2_straus4_coop_notab": dict(miller_twin=1, miller_ch=2, var_tm=4, coop_fe=2, line_tables=0, overlap=0),
-    "twin4_straus2_lane_overlap": dict(miller_twin=1, miller_ch=4, var_tm=2, coop_fe=0, line_tables=1, overlap=1),
-    "single6_straus8_lane": dict(miller_twin=0, miller_ch=6, var_tm=8, coop_fe=0, line_tables=1, overlap=0),
-    "single1_plain_coop_notab_overlap": dict(miller_twin=0, miller_ch=1, var_tm=1, coop_fe=2, line_tables=0, overlap=1),
-    "single3_straus4_coop": dict(miller_twin=0, miller_ch=3, var_tm=4, coop_fe=2, line_tables=1, overlap=0),
+    "twin6_straus8x2w5_lane": dict(miller_twin=1, miller_ch=6, var_tm=8, var_mo=2, var_w=5, coop_fe=0, line_tables=1,
+                                   overlap=0),
+    "twin2_straus4x4_coop_notab": dict(miller_twin=1, miller_ch=2, var_tm=4, var_mo=4, var_w=4, coop_fe=2,
+                                       line_tables=0, overlap=0),
+    "twin4_straus2_lane_overlap": dict(miller_twin=1, miller_ch=4, var_tm=2, var_mo=1, var_w=4, coop_fe=0,
+                                       line_tables=1, overlap=1),
+    "single6_straus8x4w5_lane": dict(miller_twin=0, miller_ch=6, var_tm=8, var_mo=4, var_w=5, coop_fe=0, line_tables=1,
+                                     overlap=0),
+    "single1_plain_coop_notab_overlap": dict(miller_twin=0, miller_ch=1, var_tm=1, var_mo=1, var_w=4, coop_fe=2,
+                                             line_tables=0, overlap=1),
+    "single3_straus4w5_coop": dict(miller_twin=0, miller_ch=3, var_tm=4, var_mo=1, var_w=5, coop_fe=2, line_tables=1,
+                                   overlap=0),
+    "twin6_straus8x2_lane": dict(miller_twin=1, miller_ch=6, var_tm=8, var_mo=2, var_w=4, coop_fe=0, line_tables=1,
+                                 overlap=0),
 }
 
 
@@ -34,7 +42,11 @@ def expected_kernels(ty, m, n, o):
             return "k_var" + tag
         ng = (terms + tm - 1) // tm
         eff = (terms + ng - 1) // ng
-        return ("k_var" if eff <= 1 else "k_var_multi4" if eff <= 4 else "k_var_multi8") + tag
+        if eff <= 1:
+            return "k_var" + tag
+        # k_var_multi<group capacity>[w5][x<outputs per lane>]: the lanes share one table build between outputs
+        return (("k_var_multi4" if eff <= 4 else "k_var_multi8") + ("w5" if o["var_w"] == 5 else "") +
+                ("x%d" % o["var_mo"] if o["var_mo"] > 1 else "") + tag)
 
     if xg:
         ex.append(var_name(m + n, ".g1"))
@@ -57,6 +69,6 @@ def test_forced_kernel_shapes_match_oracle(cname, cid, ty, shape):
 def test_forced_shapes_wide_statement(cname, cid):
     """8 x 3 PPE: 8-term Straus groups on the verifier's G1 side too (k_var_multi8.vg1), 11 pairs in the b = 1 cells
     (two twin lanes of 6 + 5), uneven Miller lanes."""
-    o = SHAPES["twin6_straus8_lane"]
-    run_batch(cid, cname, 0, 40, 8, 3, range(40), opts=o, expect=expected_kernels(0, 8, 3, o) + ["k_var_multi8.vg1"],
+    o = SHAPES["twin6_straus8x2w5_lane"]
+    run_batch(cid, cname, 0, 40, 8, 3, range(40), opts=o, expect=expected_kernels(0, 8, 3, o) + ["k_var_multi8w5x2.vg1"],
               seed=9200)
