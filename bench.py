@@ -153,8 +153,8 @@ def alu_roofline(work, ms, curve_id, dominant):
             m = items * 16 * (65535.0 / 65536.0) * cnt[g + "_madd"]  # 16-bit windows
         elif k == "k_var":
             m = lanes * cnt[g + "_smul"]
-        elif k in ("k_var_multi4", "k_var_multi8"):
-            m = items * cnt["%s_straus%s_per_term" % (g, k[-1])]
+        elif k.startswith("k_var_multi"):  # k_var_multi<4|8>[w5][x<outputs per table build>]
+            m = items * cnt["%s_straus%s_per_term" % (g, k[len("k_var_multi"):])]
         elif k == "k_red":
             m = max(items - 2 * lanes, 0) * cnt[g + "_add"] + lanes * cnt[g + "_red_tail"]
         elif name == "k_miller.twin":

@@ -149,9 +149,9 @@ static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
 struct MCost {
   double base, var, fix;
 };
-// (profiles/r1/fq_mul_counts.json: miller*_per_lane, _per_pair / _per_triple, _per_fixed_pair / _per_fixed_triple)
+// (profiles/r2/fq_mul_counts.json: miller*_per_lane, _per_pair / _per_triple, _per_fixed_pair / _per_fixed_triple)
 static inline MCost mcost(int curve, bool twin) {
-  if (curve == 0) return twin ? MCost{4536.0, 7545.0, 5848.0} : MCost{2268.0, 4621.0, 2924.0};
+  if (curve == 0) return twin ? MCost{4536.0, 7356.0, 5848.0} : MCost{2268.0, 4432.0, 2924.0};
   return twin ? MCost{4680.0, 9991.0, 7568.0} : MCost{2340.0, 6207.0, 3784.0};
 }
 static inline bool pair_fixed(bool lt, const PairRef& r) { return lt && r.q_arr == 2; }  // Q array 2 = CRS (v, W2)
@@ -412,6 +412,19 @@ static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& 
 // and `outputs` outputs per equation.  Same cost model as miller_cost: rounds of waves x lane length, lane(nt) =
 // D + P nt Fq multiplications (fits of profiles/r1/fq_mul_counts.json, the same within 3 % on both curves now that
 // both have endomorphism decompositions: G1 832 + 829 nt, G2 1000 + 2365 nt).
+// Lane-time multiplier of a launch of `waves` waves.  The Fp2 / Fp12 kernels and the BLS12-381 G1 kernels hold one
+// wave per SIMD: whole rounds while there are few.  The BN254 G1 Straus kernels come out of the compiler at 252
+// registers and run two waves per SIMD; two resident waves finish in 2 / 1.55 of the time of one (measured at 2^16:
+// k_var_multi8.g1 11.4 ms as 2048 waves against 16.7 ms as 1024 waves of twice the length).
+static double wave_rounds(const gs_ctx* c, double waves, bool g2) {
+  double r = waves / (double)c->simd_slots;
+  if (g2 || c->curve != 1) {
+    if (r <= 1.0) return 1.0;
+    return r < 4.0 ? (double)(size_t)(r + 0.999) : r;
+  }
+  const double gain = 1.55;
+  return r <= gain ? 1.0 : r / gain;
+}
 static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
   if (T < 2) return 1;
   double D = g2 ? 1000 : 832, P = g2 ? 2365 : 829;
@@ -421,9 +434,7 @@ static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
     if (c->var_tm > 0 && tm != c->var_tm) continue;
     int ng = (T + tm - 1) / tm, eff = (T + ng - 1) / ng;
     if (eff != tm && c->var_tm <= 0) continue;  // the balanced size is what runs; skip aliases
-    double waves = (double)N * outputs * ng / 64.0;
-    double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
-    if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);
+    double rounds = wave_rounds(c, (double)N * outputs * ng / 64.0, g2);
     // + the lane of k_red that folds the ng partial sums of an output (matters for large arities)
     double cost = rounds * (D + P * eff) + fold_cost((double)ng, g2 ? 29.0 + 14.0 : 16.0);
     if (best < 0 || cost < best) {
@@ -483,9 +494,7 @@ static void share_tables(const gs_ctx* c, size_t N, SidePlan& sp, bool g2) {
     for (auto& f : fam) lanes += (f.second.size() + mo - 1) / mo;
     for (int w : {4, 5}) {
       if (c->var_w > 0 && w != c->var_w) continue;
-      double waves = (double)N * lanes / 64.0;
-      double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
-      if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);
+      double rounds = wave_rounds(c, (double)N * lanes / 64.0, g2);
       int eff_mo = (int)std::min((size_t)mo, share);
       double cost = rounds * straus_lane_cost(g2, c->curve == 1, ntmax, eff_mo, w);
       if (best < 0 || cost < best) {
@@ -658,6 +667,7 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     for (size_t g0 = 0; g0 < tot; g0 += chunk) {
       size_t n = std::min(chunk, tot - g0);
       c->work_hint = (uint64_t)((double)N * sp.var.size() * ((double)n / (double)tot));  // terms
+
       RC(launch(c, kn.c_str(), kern, n, 64, tot, (int)sp.grp.size(), dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part,
                 sp.nslots, g0, (Aff<F>*)tabws));
     }

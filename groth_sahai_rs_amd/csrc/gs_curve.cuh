@@ -610,6 +610,10 @@ template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, c
 // the kernel's private frame: scratch is interleaved dword by dword across the 64 lanes of a wave, and 64 lanes reading
 // 8 different entries pull 8 rows of 256 bytes for every 256 bytes they use.  The kernels pass a lane-contiguous
 // global workspace instead (one entry = consecutive bytes of one lane).
+// (Deliberately a function of its own.  Inlined into the kernel, the BLS12-381 G1 lanes drop from 257 to 253
+// registers and become eligible for two waves per SIMD -- and the SAME lanes then take 27 ms instead of 17.7 ms at
+// 2^16 when they are launched as 1024 waves, with k_fix / k_red of the same step slower too; measured on one box,
+// profiles/r2/straus_occupancy.txt.)
 template <class C, class F, int TMAX, int W>
 GS_HD_NOINLINE void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int nt) {
   constexpr int NE = 1 << (W - 1);

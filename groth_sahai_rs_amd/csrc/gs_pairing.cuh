@@ -46,7 +46,17 @@ template <class C> GS_ML void miller_dbl(Proj2<C>& t, Line<C>& l) {
   Fp2<C> xy = mul(t.x, t.y);
   Fp2<C> b = sqr(t.y);
   Fp2<C> c = sqr(t.z);
-  Fp2<C> e = mul(twist_b3<C>(), c);                           // 3 b' Z^2
+  Fp2<C> e;                                                   // 3 b' Z^2
+  if constexpr (C::B2X3_XI_K != 0) {
+    // 3 b' = k xi with k small (BLS12-381: 12): linear operations and one value reduction (|V| < 3 k p before it)
+    // instead of an Fp2 multiplication
+    static_assert(C::B2X3_XI_K % 4 == 0 && C::B2X3_XI_K <= 12, "limb growth below: 2 x 3, then x 4");
+    Fp2<C> x = norm(mul_small(norm(mul_small(mul_xi(c), C::B2X3_XI_K / 4)), 4));
+    e.c0 = vreduce(x.c0);
+    e.c1 = vreduce(x.c1);
+  } else {
+    e = mul(twist_b3<C>(), c);
+  }
   Fp2<C> f = norm(add(dbl(e), e));                            // 9 b' Z^2
   Fp2<C> h = norm(sub(sub(sqr_l2(add(t.y, t.z)), b), c));     // 2 Y Z
   Fp2<C> j = sqr(t.x);
@@ -165,15 +175,7 @@ template <class C> GS_HD_NOINLINE void miller_line_table(Line<C>* out, const Aff
 template <class C>
 GS_HD_NOINLINE void multi_miller(Fp12<C>& fout, const Aff<Fq<C>>* ps, const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts,
                                  bool* live, const Line<C>* const* fixed = nullptr) {
-#if defined(GS_MILLER_LOCAL)
-  Fp12<C> f;
-  struct Out {
-    Fp12<C>&a, &o;
-    GS_HD ~Out() { o = a; }
-  } out_{f, fout};
-#else
-  Fp12<C>& f = fout;
-#endif
+  Fp12<C>& f = fout;  // (a local accumulator changes nothing here: 109.7 vs 110.5 ms, batched verifier at 2^16)
   f12_one(f);
   bool any = false;
   for (int k = 0; k < np; k++) {
@@ -249,18 +251,10 @@ template <class C>
 GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0out, Fp12<C>& f1out, const Aff<Fq<C>>* p0, const Aff<Fq<C>>* p1,
                                   const Aff<Fp2<C>>* qs, int np, Proj2<C>* ts, uint8_t* live,
                                   const Line<C>* const* fixed = nullptr) {
-#if defined(GS_MILLER_LOCAL)
-  Fp12<C> f0, f1;  // locals: no aliasing with the pointer arguments, the allocator decides where they live
-  struct Out {
-    Fp12<C>&a, &b, &o0, &o1;
-    GS_HD ~Out() {
-      o0 = a;
-      o1 = b;
-    }
-  } out_{f0, f1, f0out, f1out};
-#else
+  // (f0 / f1 stay behind the references: as locals the allocator turns their 336 dwords into one-dword spills and the
+  // twin kernel goes from 194 to 228 ms at 2^16; the 16-byte loads and stores through the pointers are the cheaper
+  // register file extension)
   Fp12<C>&f0 = f0out, &f1 = f1out;
-#endif
   f12_one(f0);
   f12_one(f1);
   bool any = false;

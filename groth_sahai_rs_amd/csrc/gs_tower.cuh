@@ -170,17 +170,17 @@ template <class C> GS_F6 void f6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b
   Fp2<C> t0 = sub(sub(mul_l2(add(a.c1, a.c2), add(b.c1, b.c2)), v1), v2);  // A = 3
   Fp2<C> t1 = sub(sub(mul_l2(add(a.c0, a.c1), add(b.c0, b.c1)), v0), v1);
   Fp2<C> t2 = sub(sub(mul_l2(add(a.c0, a.c2), add(b.c0, b.c2)), v0), v2);
-  r.c0 = norm(add(v0, mul_xi(norm(t0))));
+  // xi = 1 + u: xi t0 has A <= 6 and the sum A <= 7, one carry round at the end is enough; xi = 9 + u needs A ~ 1 in
+  r.c0 = norm(add(v0, mul_xi(C::XI_A == 1 ? t0 : norm(t0))));
   r.c1 = norm(add(t1, mul_xi(v2)));
   r.c2 = norm(add(t2, v1));
 }
 // a * (b0 + b1 v): 5 Fp2 multiplications
 template <class C> GS_F6 void f6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {
   Fp2<C> v0 = mul(a.c0, b0), v1 = mul(a.c1, b1);
-  Fp2<C> t0 = sub(mul_l2(add(a.c1, a.c2), b1), v1);                        // a2*b1
-  Fp2<C> t1 = sub(sub(mul_l2(add(a.c0, a.c1), add(b0, b1)), v0), v1);      // a0 b1 + a1 b0
-  Fp2<C> t2 = sub(mul_l2(add(a.c0, a.c2), b0), v0);                        // a2*b0
-  r.c0 = norm(add(v0, mul_xi(norm(t0))));
+  Fp2<C> t0 = mul(a.c2, b1), t2 = mul(a.c2, b0);                           // only a0 b1 + a1 b0 gains from Karatsuba
+  Fp2<C> t1 = sub(sub(mul_l2(add(a.c0, a.c1), add(b0, b1)), v0), v1);
+  r.c0 = norm(add(v0, mul_xi(t0)));
   r.c1 = norm(t1);
   r.c2 = norm(add(t2, v1));
 }

@@ -259,6 +259,24 @@ template <class C> struct Twin {
       case 1: jac_smul_any<C>(J2, Q[0], k[0]); break;
       case 2: if (nt <= 4) jac_msm_straus<C, F1, 4>(J1, P, k, nt); else jac_msm_straus<C, F1, 8>(J1, P, k, nt); break;
       case 3: if (nt <= 4) jac_msm_straus<C, F2, 4>(J2, Q, k, nt); else jac_msm_straus<C, F2, 8>(J2, Q, k, nt); break;
+      case 17:    // G1 / G2 Straus lane: (nt & 15) bases, window width (nt >> 8) & 15, (nt >> 12) outputs per build
+      case 18: {
+        int n = nt & 15, w = (nt >> 8) & 15, mo = nt >> 12;
+        if (op == 17) {
+          static Aff<F1> at[8 * 16];
+          F1 zb;
+          if (w == 5) jac_straus_build<C, F1, 8, 5>(at, zb, P, n); else jac_straus_build<C, F1, 8, 4>(at, zb, P, n);
+          for (int o = 0; o < mo; o++)
+            if (w == 5) jac_straus_run<C, F1, 8, 5>(J1, k, n, at, zb); else jac_straus_run<C, F1, 8, 4>(J1, k, n, at, zb);
+        } else {
+          static Aff<F2> at[8 * 16];
+          F2 zb;
+          if (w == 5) jac_straus_build<C, F2, 8, 5>(at, zb, Q, n); else jac_straus_build<C, F2, 8, 4>(at, zb, Q, n);
+          for (int o = 0; o < mo; o++)
+            if (w == 5) jac_straus_run<C, F2, 8, 5>(J2, k, n, at, zb); else jac_straus_run<C, F2, 8, 4>(J2, k, n, at, zb);
+        }
+        break;
+      }
       case 4: jac_madd(J1, J1, P[0]); break;
       case 5: jac_madd(J2, J2, Q[0]); break;
       case 6: jac_add(J1, J1, K1); break;

@@ -1,5 +1,5 @@
 """Fq multiplications per device primitive, counted by the CPU twin (the device headers compiled for the host with
--DGS_FQ28_CHECK, whose mul() increments a counter).  Output: profiles/r1/fq_mul_counts.json, read by bench.py to turn
+-DGS_FQ28_CHECK, whose mul() increments a counter).  Output: profiles/r2/fq_mul_counts.json, read by bench.py to turn
 the per-kernel work items reported by gs_prof_get_work into "useful Fq multiplications per step" (ALU roofline).
 Run from the repo root:  python tools/count_fq_muls.py"""
 import ctypes
@@ -47,6 +47,11 @@ for name in ("bls12_381", "bn254"):
         "g1_smul": avg(0, 1), "g2_smul": avg(1, 1),
         "g1_straus4_per_term": avg(2, 4) / 4, "g1_straus8_per_term": avg(2, 8) / 8,
         "g2_straus4_per_term": avg(3, 4) / 4, "g2_straus8_per_term": avg(3, 8) / 8,
+        # lanes that serve several outputs from one table build, 4- or 5-bit windows: per term and output
+        **{"%s_straus%d%s%s_per_term" % (g, cap, "w5" if w == 5 else "", "x%d" % mo if mo > 1 else ""):
+           avg(op, cap | (w << 8) | (mo << 12)) / (cap * mo)
+           for g, op in (("g1", 17), ("g2", 18)) for cap in (4, 8) for w in (4, 5) for mo in (1, 2, 4)
+           if not (w == 4 and mo == 1)},
         "g1_madd": avg(4, 2, 1), "g2_madd": avg(5, 2, 1), "g1_add": avg(6, 2, 1), "g2_add": avg(7, 2, 1),
         "g1_red_tail": avg(8, 2, 1), "g2_red_tail": avg(9, 2, 1),
         "miller_per_lane": m[0] - (m[2] - m[0]) / 2, "miller_per_pair": (m[2] - m[0]) / 2,
@@ -55,6 +60,6 @@ for name in ("bls12_381", "bn254"):
         "f12_mul": avg(11, 1, 1), "final_exp": avg(12, 1, 1), "final_exp_coop_lane": avg(13, 1, 1) / 3,
         "mads_per_fq_mul": 2 * (14 if name == "bls12_381" else 10) ** 2,
     }
-path = os.path.join(ROOT, "profiles", "r1", "fq_mul_counts.json")
+path = os.path.join(ROOT, "profiles", "r2", "fq_mul_counts.json")
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
