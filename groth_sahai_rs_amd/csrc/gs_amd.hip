@@ -14,6 +14,7 @@
 #include <mutex>
 #include <queue>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "gs_params_bls12_381.h"
@@ -214,19 +215,25 @@ static double fold_cost(double n, double unit) {
 }
 static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTask>& mt, bool twin) {
   const MCost mc = mcost(c->curve, twin);
-  double lane = 0;
+  // Lanes are task-major: a wave is 64 equations of ONE task and lasts as long as that task's lane.  A launch lasts
+  // as long as its longest lane, or -- once it is several rounds of waves -- as long as all lanes together take on the
+  // SIMD slots (waves of short tasks do not wait for those of long ones).
+  double longest = 0, all = 0;
+  const double wpt = (double)(size_t)((N + 63) / 64);  // waves per task
   for (const MillerTask& t : mt) {
     double l = mc.base;
     for (int q = 0; q < t.np; q++) l += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix : mc.var;
-    lane = l > lane ? l : lane;
+    longest = l > longest ? l : longest;
+    all += l * wpt;
   }
-  double waves = (double)(size_t)(((double)mt.size() * (double)N + 63.0) / 64.0);  // lanes are contiguous (task-major)
-  double rounds = waves <= (double)c->simd_slots ? 1.0 : waves / (double)c->simd_slots;
-  if (rounds < 4.0) rounds = (double)(size_t)(rounds + 0.999);  // whole rounds matter while there are few of them
+  double rounds = (double)mt.size() * wpt / (double)c->simd_slots;
+  double fill = all / (double)c->simd_slots;
+  if (rounds > 1.0 && rounds < 4.0) fill *= (double)(size_t)(rounds + 0.999) / rounds;  // whole rounds while few
+  double lane = rounds <= 1.0 ? longest : (fill > longest ? fill : longest);
   // + the lanes that multiply a cell's partials together (54 Fq multiplications each): k_final's own serial product
   // up to 16 of them, above that K-ary tree levels of 8 (k_cell_fold; large arities)
   double per_cell = (double)mt.size() * (twin ? 2.0 : 1.0) / 4.0;
-  return rounds * lane + fold_cost(per_cell, 54.0);
+  return lane + fold_cost(per_cell, 54.0);
 }
 // lane-cost budgets worth trying: a variable + f fixed pairs
 static std::vector<double> miller_budgets(const gs_ctx* c, bool twin) {
@@ -313,7 +320,16 @@ template <class T> static int upload(gs_ctx* c, const char* name, const std::vec
   uint64_t h = 1469598103934665603ull;
   const uint8_t* b = (const uint8_t*)v.data();
   const size_t nb = v.size() * sizeof(T);
-  for (size_t i = 0; i < nb; i++) h = (h ^ b[i]) * 1099511628211ull;
+  {  // 8 bytes per step (large-arity task tables are megabytes; the content is compared on a hit anyway)
+    size_t i = 0;
+    for (; i + 8 <= nb; i += 8) {
+      uint64_t w;
+      memcpy(&w, b + i, 8);
+      h = (h ^ w) * 1099511628211ull;
+      h ^= h >> 29;
+    }
+    for (; i < nb; i++) h = (h ^ b[i]) * 1099511628211ull;
+  }
   for (int salt = 0;; salt++) {
     char key[176];
     snprintf(key, sizeof key, "plan%s.%zu.%016llx.%d", name, v.size(), (unsigned long long)h, salt);
@@ -464,34 +480,50 @@ static void share_tables(const gs_ctx* c, size_t N, SidePlan& sp, bool g2) {
   sp.mo = 1;
   sp.w = 4;
   if (sp.tm <= 1 || sp.grp.empty()) return;
-  auto sig = [&](const GrpTask& g) {
-    std::string k((const char*)&g.nt, sizeof g.nt);
-    for (uint32_t i = 0; i < g.nt; i++) {
-      const VarTask& v = sp.var[g.first[0] + i];
-      k.append((const char*)&v.p_idx, sizeof v.p_idx);
-      k.push_back((char)v.p_arr);
-      k.push_back((char)v.neg);
+  // families of groups over the same bases, in plan order: hash of (nt, (index, array, sign) of every base), with
+  // the bases compared on a hash match (large arities have ~10^5 groups: no strings, no ordered map)
+  auto same = [&](const GrpTask& a, const GrpTask& b) {
+    if (a.nt != b.nt) return false;
+    for (uint32_t i = 0; i < a.nt; i++) {
+      const VarTask &x = sp.var[a.first[0] + i], &y = sp.var[b.first[0] + i];
+      if (x.p_idx != y.p_idx || x.p_arr != y.p_arr || x.neg != y.neg) return false;
     }
-    return k;
+    return true;
   };
-  std::map<std::string, std::vector<size_t>> fam;  // signature -> groups, in plan order
-  std::vector<std::string> order;
+  std::vector<std::vector<size_t>> fam;
+  std::unordered_map<uint64_t, std::vector<size_t>> by_hash;  // hash -> families
   int ntmax = 1;
   for (size_t i = 0; i < sp.grp.size(); i++) {
-    std::string k = sig(sp.grp[i]);
-    if (!fam.count(k)) order.push_back(k);
-    fam[k].push_back(i);
-    ntmax = std::max(ntmax, (int)sp.grp[i].nt);
+    const GrpTask& g = sp.grp[i];
+    uint64_t h = 1469598103934665603ull ^ g.nt;
+    for (uint32_t k = 0; k < g.nt; k++) {
+      const VarTask& v = sp.var[g.first[0] + k];
+      h = (h ^ (((uint64_t)v.p_idx << 16) | ((uint64_t)v.p_arr << 8) | v.neg)) * 1099511628211ull;
+    }
+    std::vector<size_t>& cand = by_hash[h];
+    size_t f = (size_t)-1;
+    for (size_t c2 : cand)
+      if (same(sp.grp[fam[c2][0]], g)) {
+        f = c2;
+        break;
+      }
+    if (f == (size_t)-1) {
+      f = fam.size();
+      fam.emplace_back();
+      cand.push_back(f);
+    }
+    fam[f].push_back(i);
+    ntmax = std::max(ntmax, (int)g.nt);
   }
   size_t share = 1;
-  for (auto& f : fam) share = std::max(share, f.second.size());
+  for (auto& f : fam) share = std::max(share, f.size());
   int best_mo = 1, best_w = 4;
   double best = -1;
   for (int mo : {1, 2, 4}) {
     if (c->var_mo > 0 && mo != c->var_mo) continue;
     if (c->var_mo <= 0 && (size_t)mo > share) continue;
     size_t lanes = 0;
-    for (auto& f : fam) lanes += (f.second.size() + mo - 1) / mo;
+    for (auto& f : fam) lanes += (f.size() + mo - 1) / mo;
     for (int w : {4, 5}) {
       if (c->var_w > 0 && w != c->var_w) continue;
       double rounds = wave_rounds(c, (double)N * lanes / 64.0, g2);
@@ -508,8 +540,7 @@ static void share_tables(const gs_ctx* c, size_t N, SidePlan& sp, bool g2) {
   sp.w = best_w;
   if (best_mo == 1) return;
   std::vector<GrpTask> merged;
-  for (const std::string& k : order) {
-    const std::vector<size_t>& f = fam[k];
+  for (const std::vector<size_t>& f : fam) {
     for (size_t b = 0; b < f.size(); b += best_mo) {
       GrpTask g = sp.grp[f[b]];
       g.no = (uint32_t)std::min((size_t)best_mo, f.size() - b);
@@ -1730,7 +1761,7 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
     if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "miller_twin: -1 (planned), 0, 1");
     c->miller_twin = value;
   } else if (k == "miller_ch") {
-    if (value < 0 || value > MILLER_CH) return fail(c, GS_ERR_ARG, "miller_ch: 0 (planned) .. 6");
+    if (value < 0 || value > MILLER_CH) return fail(c, GS_ERR_ARG, "miller_ch: 0 (planned) .. capacity of a Miller lane");
     c->miller_ch = value;
   } else if (k == "var_tm") {
     if (value < 0 || value > 8) return fail(c, GS_ERR_ARG, "var_tm: 0 (planned) .. 8");

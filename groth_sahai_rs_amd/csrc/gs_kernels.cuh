@@ -54,7 +54,10 @@ struct PairRef {
   uint8_t p_arr, q_arr, neg, pad;
   uint32_t p_idx, q_idx;
 };
-constexpr int MILLER_CH = 6;  // capacity of a Miller lane; the host picks the chunk per batch size (pick_ch)
+#ifndef GS_MILLER_CAP
+#define GS_MILLER_CAP 12
+#endif
+constexpr int MILLER_CH = GS_MILLER_CAP;  // capacity of a Miller lane; the host picks the chunk per batch size
 struct MillerTask {
   uint8_t np, b, single, pad1;  // single: only the P(0) partner is used (one accumulator)
   PairRef pr[MILLER_CH];

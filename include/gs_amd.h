@@ -71,7 +71,7 @@ void gs_ctx_destroy(gs_ctx* ctx);
 int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default stream */
 /* Planner overrides (results never change, only which kernel shapes run; tests force every shape through them):
  *   "miller_twin"  -1 planned | 0 one accumulator per Miller lane | 1 two (lines of Q shared by both G1 partners)
- *   "miller_ch"     0 planned | 1..6 pairs (triples) per Miller lane
+ *   "miller_ch"     0 planned | 1..12 pairs (triples) per Miller lane
  *   "var_tm"        0 planned | 1..8 variable-base terms per Straus lane
  *   "var_mo"        0 planned | 1, 2, 4 outputs over the same bases served by one lane's table build
  *   "var_w"         0 planned | 4, 5 window width of the Straus lanes (8 or 16 table entries per base)
