@@ -138,7 +138,7 @@ class Engine:
         self._chk(self.lib.gs_sync(self.ctx))
 
     def set_option(self, key, value):
-        """Planner override (include/gs_amd.h, gs_set_option): miller_twin, miller_ch, var_tm, var_mo, var_w, coop_fe, line_tables,
+        """Planner override (include/gs_amd.h, gs_set_option): miller_twin, miller_ch, var_tm, var_mo, var_w, red_k, coop_fe, line_tables,
         overlap.  Results never change, only which kernel shapes run."""
         self._chk(self.lib.gs_set_option(self.ctx, key.encode(), int(value)))
 

@@ -94,6 +94,7 @@ struct gs_ctx {
   size_t simd_slots = 1024;
   // planner overrides (gs_set_option; 0 / -1 = planned per batch)
   int var_tm = 0;
+  int red_k = 0;  // outputs per reduction lane (1, 2, 4); 0 = planned
   int var_mo = 0, var_w = 0;  // outputs per Straus lane (1, 2, 4) and its window width (4, 5); 0 = planned
   int miller_ch = 0, miller_twin = -1;
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
@@ -219,7 +220,8 @@ static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTas
   // as long as its longest lane, or -- once it is several rounds of waves -- as long as all lanes together take on the
   // SIMD slots (waves of short tasks do not wait for those of long ones).
   double longest = 0, all = 0;
-  const double wpt = (double)(size_t)((N + 63) / 64);  // waves per task
+  // waves per task (below 64 equations a wave holds several tasks: a fraction of a wave each)
+  const double wpt = N >= 64 ? (double)(size_t)((N + 63) / 64) : (double)N / 64.0;
   for (const MillerTask& t : mt) {
     double l = mc.base;
     for (int q = 0; q < t.np; q++) l += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix : mc.var;
@@ -647,7 +649,12 @@ template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLau
   const RedTask* dred;
   RC(upload(c, (r.tag + ".red").c_str(), red, &dred));
   c->work_hint = N * (uint64_t)nslots;  // partial sums folded
-  return launch(c, r.name.c_str(), k_red<C, F>, N * r.nred, 64, N * r.nred, (int)r.nred, dred, part, nslots, r.outs);
+  // outputs per lane (one inversion each lane): as many as still leave the launch a full round of waves
+  int K = 1;
+  while (K < RED_K && K * 2 <= (int)r.nred && (N * ((r.nred + 2 * K - 1) / (2 * K)) + 63) / 64 >= c->simd_slots) K *= 2;
+  if (c->red_k > 0) K = std::min(c->red_k, RED_K);
+  size_t lanes = N * ((r.nred + K - 1) / K);
+  return launch(c, r.name.c_str(), k_red<C, F>, lanes, 64, lanes, (int)r.nred, dred, part, nslots, r.outs, K);
 }
 template <class C, class F>
 static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
@@ -1715,6 +1722,7 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
   if (const char* e = getenv("GS_VAR_TM")) c->var_tm = atoi(e);
   if (const char* e = getenv("GS_VAR_MO")) c->var_mo = atoi(e);
   if (const char* e = getenv("GS_VAR_W")) c->var_w = atoi(e);
+  if (const char* e = getenv("GS_RED_K")) c->red_k = atoi(e);
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return GS_ERR_DEVICE;
@@ -1772,6 +1780,9 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
   } else if (k == "var_w") {
     if (value != 0 && value != 4 && value != 5) return fail(c, GS_ERR_ARG, "var_w: 0 (planned), 4, 5");
     c->var_w = value;
+  } else if (k == "red_k") {
+    if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_ARG, "red_k: 0 (planned), 1, 2, 4");
+    c->red_k = value;
   } else if (k == "coop_fe") {
     if (value < 0 || value > 2) return fail(c, GS_ERR_ARG, "coop_fe: 0 never, 1 planned, 2 always");
     c->coop_fe = value;

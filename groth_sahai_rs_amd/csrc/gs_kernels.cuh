@@ -526,28 +526,43 @@ __global__ void __launch_bounds__(64, GS_WPE) k_fix(size_t total, int ntask, con
   part[e * nslots + t.slot] = acc;
 }
 
+// One lane = up to RED_K consecutive outputs (two points each) and ONE inversion for all of them (Montgomery's trick
+// over their Z coordinates): the inversion is most of this kernel (496 of ~530 Fq multiplications per output in G1).
+constexpr int RED_K = 4;
 template <class C, class F>
 __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, const RedTask* tasks, const Jac<F>* part,
-                                            int nslots, OutTab outs) {
+                                            int nslots, OutTab outs, int K) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
-  size_t e = g / ntask;
-  RedTask t = tasks[g % ntask];
+  const int nl = (ntask + K - 1) / K;  // lanes per equation
+  size_t e = g / nl;
+  int t0 = (int)(g % nl) * K, nt = ntask - t0 < K ? ntask - t0 : K;
   const Jac<F>* P = part + e * nslots;
-  Jac<F> s0 = P[t.b0], s1 = P[t.b1];
-  for (uint32_t i = t.b0 + 1; i < t.e0; i++) jac_add(s0, s0, P[i]);
-  for (uint32_t i = t.b1 + 1; i < t.e1; i++) jac_add(s1, s1, P[i]);
-  // one inversion for both components
-  bool i0 = is_zero_limbs(s0.z), i1 = is_zero_limbs(s1.z);
-  F z0 = i0 ? one_of<F>() : s0.z, z1 = i1 ? one_of<F>() : s1.z;
-  F zi = inv(mul(z0, z1));
-  F zi0 = mul(zi, z1), zi1 = mul(zi, z0);
-  Aff<F> a0, a1;
-  jac_to_aff_zinv(a0, s0, zi0);
-  jac_to_aff_zinv(a1, s1, zi1);
-  uint8_t* o = outs.base[t.out_arr] + e * outs.stride[t.out_arr] + 2 * (size_t)t.out_idx * AFFB(C, F);
-  aff_store<C>(o, a0);
-  aff_store<C>(o + AFFB(C, F), a1);
+  Jac<F> s[2 * RED_K];
+  F pre[2 * RED_K];  // pre[i] = z_0 ... z_(i-1) (identities count as 1)
+  F acc = one_of<F>();
+  for (int k = 0; k < nt; k++) {
+    RedTask t = tasks[t0 + k];
+    Jac<F> s0 = P[t.b0], s1 = P[t.b1];
+    for (uint32_t i = t.b0 + 1; i < t.e0; i++) jac_add(s0, s0, P[i]);
+    for (uint32_t i = t.b1 + 1; i < t.e1; i++) jac_add(s1, s1, P[i]);
+    s[2 * k] = s0;
+    s[2 * k + 1] = s1;
+    pre[2 * k] = acc;
+    if (!is_zero_limbs(s0.z)) acc = mul(acc, s0.z);
+    pre[2 * k + 1] = acc;
+    if (!is_zero_limbs(s1.z)) acc = mul(acc, s1.z);
+  }
+  F suf = inv(acc);  // 1 / (z_0 ... z_(2 nt - 1))
+  for (int i = 2 * nt - 1; i >= 0; i--) {
+    RedTask t = tasks[t0 + i / 2];
+    Aff<F> a;
+    F zi = mul(suf, pre[i]);  // 1 / z_i
+    if (!is_zero_limbs(s[i].z)) suf = mul(suf, s[i].z);
+    jac_to_aff_zinv(a, s[i], zi);  // (identity -> (0, 0), zi unused)
+    uint8_t* o = outs.base[t.out_arr] + e * outs.stride[t.out_arr] + (2 * (size_t)t.out_idx + (i & 1)) * AFFB(C, F);
+    aff_store<C>(o, a);
+  }
 }
 
 // Large arities (benches/bench.rs:451-498, m = n = 334): an output is the sum of hundreds of partial slots.  k_red

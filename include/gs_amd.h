@@ -75,11 +75,12 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "var_tm"        0 planned | 1..8 variable-base terms per Straus lane
  *   "var_mo"        0 planned | 1, 2, 4 outputs over the same bases served by one lane's table build
  *   "var_w"         0 planned | 4, 5 window width of the Straus lanes (8 or 16 table entries per base)
+ *   "red_k"         0 planned | 1, 2, 4 outputs per reduction lane (one inversion per lane)
  *   "coop_fe"       0 one lane per final exponentiation | 1 planned | 2 always the 3-lane cooperative form
  *   "line_tables"   1 CRS G2 arguments read precomputed Miller lines | 0 they are stepped like any other point
  *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream
  * The same knobs are read ONCE at gs_ctx_create from the environment for experiments without recompiling the caller:
- * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_VAR_MO, GS_VAR_W, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP (same values).
+ * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_VAR_MO, GS_VAR_W, GS_RED_K, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP (same values).
  * Unset = planned. */
 int gs_set_option(gs_ctx* ctx, const char* key, int value);
 int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the context's stream */

@@ -1,7 +1,7 @@
 """Every kernel SHAPE the planner can pick is compared with the C oracle.
 
 The planner (csrc/gs_amd.hip: miller_cost, pick_tm, coop_fe) switches kernels with the batch size: twin-accumulator
-Miller lanes, 1..12 pairs per lane, Straus groups of 4 / 8 terms (one to four outputs per table build, 4- or 5-bit windows), one-lane or 3-lane final exponentiation, table-reading
+Miller lanes, 1..12 pairs per lane, Straus groups of 4 / 8 terms (one to four outputs per table build, 4- or 5-bit windows), one, two or four outputs per inversion in the reductions, one-lane or 3-lane final exponentiation, table-reading
 or stepping CRS pairs, side streams.  At the small N the oracle can follow, the planner alone would only ever choose
 the small-batch shapes; here every shape is FORCED through gs_set_option, all four equation types, both curves, every
 equation of the batch bit-exact (commitments, pi, theta) and verdict-exact against oracle/gs_ref.c, and the library's
@@ -15,19 +15,19 @@ pytestmark = pytest.mark.gpu
 
 # name -> options; chosen so that every value of every knob occurs with both values of its neighbours
 SHAPES = {
-    "twin6_straus8x2w5_lane": dict(miller_twin=1, miller_ch=6, var_tm=8, var_mo=2, var_w=5, coop_fe=0, line_tables=1,
+    "twin6_straus8x2w5_lane": dict(red_k=4, miller_twin=1, miller_ch=6, var_tm=8, var_mo=2, var_w=5, coop_fe=0, line_tables=1,
                                    overlap=0),
-    "twin2_straus4x4_coop_notab": dict(miller_twin=1, miller_ch=2, var_tm=4, var_mo=4, var_w=4, coop_fe=2,
+    "twin2_straus4x4_coop_notab": dict(red_k=2, miller_twin=1, miller_ch=2, var_tm=4, var_mo=4, var_w=4, coop_fe=2,
                                        line_tables=0, overlap=0),
-    "twin4_straus2_lane_overlap": dict(miller_twin=1, miller_ch=4, var_tm=2, var_mo=1, var_w=4, coop_fe=0,
+    "twin4_straus2_lane_overlap": dict(red_k=1, miller_twin=1, miller_ch=4, var_tm=2, var_mo=1, var_w=4, coop_fe=0,
                                        line_tables=1, overlap=1),
-    "single6_straus8x4w5_lane": dict(miller_twin=0, miller_ch=6, var_tm=8, var_mo=4, var_w=5, coop_fe=0, line_tables=1,
+    "single6_straus8x4w5_lane": dict(red_k=2, miller_twin=0, miller_ch=6, var_tm=8, var_mo=4, var_w=5, coop_fe=0, line_tables=1,
                                      overlap=0),
-    "single1_plain_coop_notab_overlap": dict(miller_twin=0, miller_ch=1, var_tm=1, var_mo=1, var_w=4, coop_fe=2,
+    "single1_plain_coop_notab_overlap": dict(red_k=4, miller_twin=0, miller_ch=1, var_tm=1, var_mo=1, var_w=4, coop_fe=2,
                                              line_tables=0, overlap=1),
-    "single9_straus4w5_coop": dict(miller_twin=0, miller_ch=9, var_tm=4, var_mo=1, var_w=5, coop_fe=2, line_tables=1,
+    "single9_straus4w5_coop": dict(red_k=1, miller_twin=0, miller_ch=9, var_tm=4, var_mo=1, var_w=5, coop_fe=2, line_tables=1,
                                    overlap=0),
-    "twin12_straus8x2_lane": dict(miller_twin=1, miller_ch=12, var_tm=8, var_mo=2, var_w=4, coop_fe=0, line_tables=1,
+    "twin12_straus8x2_lane": dict(red_k=4, miller_twin=1, miller_ch=12, var_tm=8, var_mo=2, var_w=4, coop_fe=0, line_tables=1,
                                  overlap=0),
 }
 
