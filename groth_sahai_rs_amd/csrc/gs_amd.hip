@@ -95,6 +95,7 @@ struct gs_ctx {
   // planner overrides (gs_set_option; 0 / -1 = planned per batch)
   int var_tm = 0;
   int red_k = 0;  // outputs per reduction lane (1, 2, 4); 0 = planned
+  int var_ws_lanes = 0;  // Straus lanes per launch (their table workspace is 3.5 .. 28 KB each); 0 = 2^19
   int var_mo = 0, var_w = 0;  // outputs per Straus lane (1, 2, 4) and its window width (4, 5); 0 = planned
   int miller_ch = 0, miller_twin = -1;
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
@@ -694,7 +695,7 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     // the lanes' Straus tables: lane-contiguous global workspace (see jac_msm_straus_at), at most VAR_WS_LANES lanes
     // of it; a larger batch goes in several launches over the same workspace
     const int tmax = sp.tm <= 4 ? 4 : 8;
-    const size_t chunk = std::min(tot, VAR_WS_LANES);
+    const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes : VAR_WS_LANES);
     void* tabws;
     RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * sizeof(Aff<F>), &tabws));
     // kernel name: k_var_multi<TMAX>[w5][x<outputs per lane>]
@@ -1780,6 +1781,9 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
   } else if (k == "var_w") {
     if (value != 0 && value != 4 && value != 5) return fail(c, GS_ERR_ARG, "var_w: 0 (planned), 4, 5");
     c->var_w = value;
+  } else if (k == "var_ws_lanes") {
+    if (value < 0 || (value > 0 && value < 64) || value % 64) return fail(c, GS_ERR_ARG, "var_ws_lanes: 0 or a multiple of 64");
+    c->var_ws_lanes = value;
   } else if (k == "red_k") {
     if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_ARG, "red_k: 0 (planned), 1, 2, 4");
     c->red_k = value;

@@ -65,6 +65,13 @@ def test_forced_kernel_shapes_match_oracle(cname, cid, ty, shape):
     run_batch(cid, cname, ty, N, m, n, range(N), opts=o, expect=expected_kernels(ty, m, n, o), seed=9100 + ty)
 
 
+def test_straus_workspace_smaller_than_the_batch():
+    """The Straus lanes' table workspace is bounded (var_ws_lanes); a batch with more lanes runs as several launches
+    over the same workspace: 66 equations x 2 groups in chunks of 64 lanes, ragged last chunk."""
+    o = dict(SHAPES["twin6_straus8x2w5_lane"], var_ws_lanes=64)
+    run_batch(0, "bls12_381", 0, 66, 4, 4, range(66), opts=o, expect=expected_kernels(0, 4, 4, o), seed=9300)
+
+
 @pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])
 def test_forced_shapes_wide_statement(cname, cid):
     """8 x 3 PPE: 8-term Straus groups on the verifier's G1 side too (k_var_multi8.vg1), 11 pairs in the b = 1 cells

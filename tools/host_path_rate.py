@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import groth_sahai_rs_amd as gs
 from groth_sahai_rs_amd.workload import Workload
 
-N = 4096
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = gs.Engine(0, 0)
 wl = Workload(eng, N=N)
 h = lambda t: t.cpu().numpy()
