@@ -427,6 +427,16 @@ static void add_var_terms(SidePlan& sp, const std::vector<VarTask>& terms, int& 
     slot++;
   }
 }
+// Lane cost of the joint MSM in Fq multiplications: one table build of `nt` bases (2^(w-1) entries each: doublings,
+// mixed additions, 7 multiplications per entry for the common denominator) + `no` main loops (w doublings per window,
+// one mixed addition per non-zero digit, the endomorphism on the looked-up entry).
+static double straus_lane_cost(bool g2, bool bn, int nt, int no, int w) {
+  const double madd = g2 ? 29.0 : 11.0, dbl = g2 ? 16.0 : 8.0, gz = g2 ? 21.0 : 7.0, endo = g2 ? 4.0 : 0.5;
+  const int ns = g2 ? 4 : 2, nl = g2 ? (bn ? 3 : 2) : (bn ? 5 : 4), nd = (32 * nl + w - 1) / w + 1, ne = 1 << (w - 1);
+  double build = nt * (ne / 2 * dbl + (ne / 2 - 1) * madd + ne * gz);
+  double run = (nd - 1) * w * dbl + (double)nt * ns * (nd - 0.5) * (1.0 - 1.0 / (2 * ne)) * (madd + endo);
+  return build + no * run;
+}
 // Variable-base terms per lane (joint Straus MSM, shared doubling chain) for a side with `T` terms per output
 // and `outputs` outputs per equation.  Same cost model as miller_cost: rounds of waves x lane length, lane(nt) =
 // D + P nt Fq multiplications (fits of profiles/r1/fq_mul_counts.json, the same within 3 % on both curves now that
@@ -444,36 +454,40 @@ static double wave_rounds(const gs_ctx* c, double waves, bool g2) {
   const double gain = 1.55;
   return r <= gain ? 1.0 : r / gain;
 }
-static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2) {
+static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2, int share) {
+  // `share` of the `outputs` run over the same bases (share_tables() can give them one table build per lane): the
+  // group size is chosen together with the outputs per lane and the window width that share_tables() will then pick
   if (T < 2) return 1;
-  double D = g2 ? 1000 : 832, P = g2 ? 2365 : 829;
+  if (c->var_tm > 0) {  // forced: the balanced group size is what runs
+    int ng = (T + c->var_tm - 1) / c->var_tm;
+    return (T + ng - 1) / ng;
+  }
   int best_tm = 1;
   double best = -1;
   for (int tm = 1; tm <= 8; tm++) {
-    if (c->var_tm > 0 && tm != c->var_tm) continue;
     int ng = (T + tm - 1) / tm, eff = (T + ng - 1) / ng;
-    if (eff != tm && c->var_tm <= 0) continue;  // the balanced size is what runs; skip aliases
-    double rounds = wave_rounds(c, (double)N * outputs * ng / 64.0, g2);
-    // + the lane of k_red that folds the ng partial sums of an output (matters for large arities)
-    double cost = rounds * (D + P * eff) + fold_cost((double)ng, g2 ? 29.0 + 14.0 : 16.0);
-    if (best < 0 || cost < best) {
-      best = cost;
-      best_tm = eff;
+    if (eff != tm) continue;  // the balanced size is what runs; skip aliases
+    for (int mo : {1, 2, 4}) {
+      if (mo > 1 && (eff < 2 || mo > share)) continue;  // one-term lanes are k_var: no sharing
+      if (c->var_mo > 0 && mo != c->var_mo && !(eff < 2 && mo == 1)) continue;
+      for (int w : {4, 5}) {
+        if (w == 5 && eff < 2) continue;
+        if (c->var_w > 0 && w != c->var_w && eff >= 2) continue;
+        double lanes = (double)N * ((double)outputs / mo) * ng;
+        double rounds = wave_rounds(c, lanes / 64.0, g2);
+        // + the lane of k_red that folds the ng partial sums of an output (matters for large arities)
+        double cost = rounds * straus_lane_cost(g2, c->curve == 1, eff, mo, w) +
+                      fold_cost((double)ng, g2 ? 29.0 + 14.0 : 16.0);
+        if (best < 0 || cost < best) {
+          best = cost;
+          best_tm = eff;
+        }
+      }
     }
   }
   return best_tm;
 }
 
-// Lane cost of the joint MSM in Fq multiplications: one table build of `nt` bases (2^(w-1) entries each: doublings,
-// mixed additions, 7 multiplications per entry for the common denominator) + `no` main loops (w doublings per window,
-// one mixed addition per non-zero digit, the endomorphism on the looked-up entry).
-static double straus_lane_cost(bool g2, bool bn, int nt, int no, int w) {
-  const double madd = g2 ? 29.0 : 11.0, dbl = g2 ? 16.0 : 8.0, gz = g2 ? 21.0 : 7.0, endo = g2 ? 4.0 : 0.5;
-  const int ns = g2 ? 4 : 2, nl = g2 ? (bn ? 3 : 2) : (bn ? 5 : 4), nd = (32 * nl + w - 1) / w + 1, ne = 1 << (w - 1);
-  double build = nt * (ne / 2 * dbl + (ne / 2 - 1) * madd + ne * gz);
-  double run = (nd - 1) * w * dbl + (double)nt * ns * (nd - 0.5) * (1.0 - 1.0 / (2 * ne)) * (madd + endo);
-  return build + no * run;
-}
 // Groups with the same bases (same arrays, indices and signs in the same order) become ONE lane of up to `mo` outputs
 // that builds its tables once: the proof elements of a side share their constants and variables, the columns of
 // Gamma^T c share the commitments.  Picks (mo, w) by the cost model of pick_tm unless overridden.
@@ -888,7 +902,7 @@ template <class C> struct Impl {
     // G1 side: xcoms (m) + theta (ky).  constants A (len n) multiply S; Phi multiplies X; fixed part T.
     {
       SidePlan sp;
-      sp.tm = xg ? pick_tm(c, N, m + n, ky, false) : 1;
+      sp.tm = xg ? pick_tm(c, N, m + n, ky, false, ky) : 1;
       build_side(sp, xcoms != nullptr, m, n, xg, kx, ky, pm.RC, pm.XC, pm.SC, pm.PHI, pm.TC, pm.SIG);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -910,7 +924,7 @@ template <class C> struct Impl {
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
     {
       SidePlan sp;
-      sp.tm = yg ? pick_tm(c, N, m + n, kx, true) : 1;
+      sp.tm = yg ? pick_tm(c, N, m + n, kx, true, kx) : 1;
       build_side(sp, ycoms != nullptr, n, m, yg, ky, kx, pm.SC, pm.YC, pm.RC, pm.PSI, pm.OM, pm.RHO);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -1141,7 +1155,7 @@ template <class C> struct Impl {
         c->miller_choice[key] = std::make_pair(twin, budget);
       }
     }
-    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false), c->line_tables);
+    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false, n), c->line_tables);
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));

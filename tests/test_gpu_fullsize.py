@@ -23,8 +23,8 @@ def spread(N, k=16):
     return sorted(s)
 
 
-# (k_var_multi8*: the planner also picks the window width and the outputs per table build, see share_tables)
-LARGE = ["k_miller.twin", "k_final", "k_var_multi8*.g1", "k_var_multi8*.g2"]
+# (k_var_multi*: the planner picks the group size together with the window width and the outputs per table build)
+LARGE = ["k_miller.twin", "k_final", "k_var_multi*.g1", "k_var_multi*.g2"]
 
 
 def test_config2_mixed_2p16_bls12_381():

@@ -16,7 +16,7 @@ tools/pmc_pass.sh $TAG/pmc_2p12_ppe --log2n 12
 echo "pmc 2^12 done"
 python3 bench.py > $O/bench_default.json
 echo "bench default done"
-for args in "--log2n 14" "--log2n 16 --mode rlc" "--log2n 14 --type 1" "--log2n 14 --type 2" "--log2n 14 --type 3"; do
+for args in "--log2n 15" "--log2n 17" "--log2n 14" "--log2n 16 --mode rlc" "--log2n 14 --type 1" "--log2n 14 --type 2" "--log2n 14 --type 3"; do
   name=$(echo "$args" | tr -d ' -')
   python3 bench.py --no-cpu --no-also --steps 3 --warmup 1 $args > $O/bench_$name.json
   echo "done $name"
