@@ -301,6 +301,91 @@ def gen_fp2sqr_call(L):
     return "\n".join(o), len(sub_body_fp2sqr(L))
 
 
+# ---- Fp2 dot product of n pairs as one subroutine: c = sum_t a_t b_t, one reduction per output -----------------------
+# Pair t: a_t0 v(4tL).., a_t1 v(4tL+L).., b_t0 v(4tL+2L).., b_t1 v(4tL+3L).. (preserved) -> c0 v(4nL).., c1 v(4nL+L)..;
+# -a_t1 v(4nL+2L+tL).., two accumulators after them.  Contract: sum_t A_at A_bt <= 4 (2n products of L terms plus L
+# reduction terms per column of a signed 64-bit accumulator).  (4n + 2) L^2 multiply-adds for what n separate products
+# spend 6n L^2 on: the sparse Miller-line products are six of these with n = 3 and nothing else.
+def sub_body_fp2dot(L, n):
+    A0 = lambda t, i: "v%d" % (4 * t * L + i)
+    A1 = lambda t, i: "v%d" % (4 * t * L + L + i)
+    B0 = lambda t, i: "v%d" % (4 * t * L + 2 * L + i)
+    B1 = lambda t, i: "v%d" % (4 * t * L + 3 * L + i)
+    R0 = lambda i: "v%d" % (4 * n * L + i)
+    R1 = lambda i: "v%d" % (4 * n * L + L + i)
+    N1 = lambda t, i: "v%d" % (4 * n * L + 2 * L + t * L + i)
+    base = 4 * n * L + 2 * L + n * L
+    P = lambda i: "s%d" % (40 + i)
+    INV = "s%d" % (40 + L)
+    AC0, LO0 = "v[%d:%d]" % (base, base + 1), "v%d" % base
+    AC1, LO1 = "v[%d:%d]" % (base + 2, base + 3), "v%d" % (base + 2)
+    out = []
+    for t in range(n):
+        for i in range(L):
+            out.append("v_sub_u32 %s, 0, %s" % (N1(t, i), A1(t, i)))
+    f0 = f1 = True
+    for k in range(2 * L - 1):
+        for i in range(max(0, k - L + 1), min(k, L - 1) + 1):
+            j = k - i
+            for t in range(n):
+                out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC0, A0(t, i), B0(t, j), "0" if f0 else AC0))
+                f0 = False
+                out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC1, A0(t, i), B1(t, j), "0" if f1 else AC1))
+                f1 = False
+                out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC0, N1(t, i), B1(t, j), AC0))
+                out.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (AC1, A1(t, i), B0(t, j), AC1))
+        for i in range(max(0, k - L + 1), min(k - 1, L - 1) + 1):
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC0, R0(i), P(k - i), AC0))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC1, R1(i), P(k - i), AC1))
+        if k < L:
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R0(k), LO0, INV))
+            out.append("v_mul_lo_u32 %s, %s, %s" % (R1(k), LO1, INV))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R0(k), R0(k)))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R1(k), R1(k)))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC0, R0(k), P(0), AC0))
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (AC1, R1(k), P(0), AC1))
+        else:
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R0(k - L), LO0))
+            out.append("v_and_b32 %s, 0xfffffff, %s" % (R1(k - L), LO1))
+        out.append("v_ashrrev_i64 %s, 28, %s" % (AC0, AC0))
+        out.append("v_ashrrev_i64 %s, 28, %s" % (AC1, AC1))
+    out.append("v_mov_b32 %s, %s" % (R0(L - 1), LO0))
+    out.append("v_mov_b32 %s, %s" % (R1(L - 1), LO1))
+    out.append("s_setpc_b64 s[34:35]")
+    return out
+
+
+def gen_fp2dot_call(L, n):
+    NLT = "\\n\\t"
+    sym = "gs_fp2dot%d_28_sub_%d" % (n, L)
+    o = ['extern "C" __device__ void %s();' % sym]
+    body = ["s_branch .Lgs_skipd%d_%d_%%=" % (n, L), ".p2align 8", ".globl %s" % sym, ".type %s,@function" % sym, sym + ":"]
+    body += sub_body_fp2dot(L, n) + [".Lgs_skipd%d_%d_%%=:" % (n, L)]
+    o.append('extern "C" __device__ __attribute__((used, noinline)) void gs_fp2dot%d_28_sub_holder_%d() {' % (n, L))
+    o.append('  asm volatile("%s" ::: "memory");' % NLT.join(body))
+    o.append("}")
+    outs = ", ".join('"={v%d}"(r0[%d])' % (4 * n * L + i, i) for i in range(L)) + ", " + \
+        ", ".join('"={v%d}"(r1[%d])' % (4 * n * L + L + i, i) for i in range(L))
+    ins = []
+    sig = []
+    for t in range(n):
+        for q, nm in enumerate(("a%d0" % t, "a%d1" % t, "b%d0" % t, "b%d1" % t)):
+            ins += ['"{v%d}"(%s[%d])' % (4 * t * L + q * L + i, nm, i) for i in range(L)]
+            sig.append("const int32_t (&%s)[%d]" % (nm, L))
+    ins += ['"{s%d}"(C::P28[%d])' % (40 + i, i) for i in range(L)] + ['"{s%d}"(C::P28_INV)' % (40 + L)]
+    nin = 4 * n * L + L + 1
+    ins.append('"s"((uint64_t)(uintptr_t)&%s)' % sym)
+    clob = ['"v%d"' % (4 * n * L + 2 * L + i) for i in range(n * L + 4)] + ['"vcc"', '"s34"', '"s35"']
+    o.append("template <class C> __device__ __forceinline__ void fp2dot%d_28_call_%d(int32_t (&r0)[%d], int32_t (&r1)[%d], %s) {"
+             % (n, L, L, L, ", ".join(sig)))
+    o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (2 * L + nin))
+    o.append("      : %s" % outs)
+    o.append("      : %s" % ", ".join(ins))
+    o.append("      : %s);" % ", ".join(clob))
+    o.append("}")
+    return "\n".join(o), len(sub_body_fp2dot(L, n))
+
+
 def gen_calls(L):
     NL = "\\n\\t"  # the two escapes as they must appear inside the C string literal
     o = []
@@ -357,6 +442,9 @@ def main():
         o.append(src)
         src, cnt = gen_fp2sqr_call(L)
         o.append("// Fp2 squaring, L = %d: %d instructions" % (L, cnt))
+        o.append(src)
+        src, cnt = gen_fp2dot_call(L, 3)
+        o.append("// Fp2 dot product of 3 pairs, L = %d: %d instructions" % (L, cnt))
         o.append(src)
     o.append("#endif")
     with open(os.path.join(here, "gs_mul28_asm.h"), "w") as f:

@@ -391,6 +391,89 @@ template <class C> GS_HD void fp2mul28(Fq28<C>& r0, Fq28<C>& r1, const Fq28<C>& 
 #endif
 }
 
+// ---- Fp2 dot product kernel: c = a0 b0 + a1 b1 + a2 b2 in Fp2, ONE Montgomery reduction per output ----------------
+// (gs_mul28_asm.h, "Fp2 dot product of 3 pairs").  14 L^2 multiply-adds for what three separate products spend
+// 18 L^2 on, and the sum needs no lazy additions or carry round afterwards: the sparse Miller-line products are six of
+// these (gs_tower.cuh).  Contract: sum_t A_at A_bt <= 4; the CPU twin asserts it per column.  a / b: three (re, im).
+template <class C, class T> GS_HD void fp2dot3_28_generic(T* r0, T* r1, const T* const* a, const T* const* b) {
+  constexpr int L = C::L;
+  uint32_t m0[L], m1[L];
+#if defined(GS_FQ28_CHECK)
+  __int128 acc0 = 0, acc1 = 0;
+#else
+  int64_t acc0 = 0, acc1 = 0;
+#endif
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (j < 0 || j >= L) continue;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        acc0 += (int64_t)a[2 * t][i] * b[2 * t][j] - (int64_t)a[2 * t + 1][i] * b[2 * t + 1][j];
+        acc1 += (int64_t)a[2 * t][i] * b[2 * t + 1][j] + (int64_t)a[2 * t + 1][i] * b[2 * t][j];
+      }
+      if (j >= 1 && i < k) {
+        acc0 += (int64_t)(int32_t)m0[i] * C::P28[j];
+        acc1 += (int64_t)(int32_t)m1[i] * C::P28[j];
+      }
+    }
+#if defined(GS_FQ28_CHECK)
+    {
+      const __int128 lim = (__int128)1 << 63;
+      if (acc0 >= lim || acc0 < -lim || acc1 >= lim || acc1 < -lim) {
+        fprintf(stderr, "Fp2 dot product: column accumulator leaves the signed 64-bit range (sum A_a A_b > 4)\n");
+        abort();
+      }
+    }
+#endif
+    if (k < L) {
+      m0[k] = ((((uint32_t)acc0) & (uint32_t)M28) * C::P28_INV) & (uint32_t)M28;
+      m1[k] = ((((uint32_t)acc1) & (uint32_t)M28) * C::P28_INV) & (uint32_t)M28;
+      acc0 += (int64_t)(int32_t)m0[k] * C::P28[0];
+      acc1 += (int64_t)(int32_t)m1[k] * C::P28[0];
+    } else {
+      r0[k - L] = (T)(((uint32_t)acc0) & (uint32_t)M28);
+      r1[k - L] = (T)(((uint32_t)acc1) & (uint32_t)M28);
+    }
+    acc0 >>= 28;
+    acc1 >>= 28;
+  }
+  r0[L - 1] = (T)acc0;
+  r1[L - 1] = (T)acc1;
+}
+// r = a0 b0 + a1 b1 + a2 b2 ; every operand as (re, im)
+template <class C>
+GS_HD void fp2dot3_28(Fq28<C>& r0, Fq28<C>& r1, const Fq28<C>& a00, const Fq28<C>& a01, const Fq28<C>& b00,
+                      const Fq28<C>& b01, const Fq28<C>& a10, const Fq28<C>& a11, const Fq28<C>& b10, const Fq28<C>& b11,
+                      const Fq28<C>& a20, const Fq28<C>& a21, const Fq28<C>& b20, const Fq28<C>& b21) {
+#if defined(GS_FQ28_CHECK)
+  fq28_mul_counter().fetch_add(7, std::memory_order_relaxed);  // 14 L^2 multiply-adds = 7 products' worth
+  for (const Fq28<C>* x : {&a00, &a01, &b00, &b01, &a10, &a11, &b10, &b11, &a20, &a21, &b20, &b21}) {
+    int64_t t = x->v[C::L - 1] < 0 ? -(int64_t)x->v[C::L - 1] : x->v[C::L - 1];
+    if (t >= (1 << 26)) {
+      fprintf(stderr, "Fp2 dot product: operand value out of range (top limb %lld)\n", (long long)t);
+      abort();
+    }
+  }
+  const limb_t* a[6] = {a00.v, a01.v, a10.v, a11.v, a20.v, a21.v};
+  const limb_t* b[6] = {b00.v, b01.v, b10.v, b11.v, b20.v, b21.v};
+  fp2dot3_28_generic<C, limb_t>(r0.v, r1.v, a, b);
+  GS_CHK_LIMBS(r0)
+  GS_CHK_LIMBS(r1)
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM) && !defined(GS_NO_ASM_CALL)
+  if constexpr (C::L == 14)
+    fp2dot3_28_call_14<C>(r0.v, r1.v, a00.v, a01.v, b00.v, b01.v, a10.v, a11.v, b10.v, b11.v, a20.v, a21.v, b20.v, b21.v);
+  else
+    fp2dot3_28_call_10<C>(r0.v, r1.v, a00.v, a01.v, b00.v, b01.v, a10.v, a11.v, b10.v, b11.v, a20.v, a21.v, b20.v, b21.v);
+#else
+  const int32_t* a[6] = {a00.v, a01.v, a10.v, a11.v, a20.v, a21.v};
+  const int32_t* b[6] = {b00.v, b01.v, b10.v, b11.v, b20.v, b21.v};
+  fp2dot3_28_generic<C, int32_t>(r0.v, r1.v, a, b);
+#endif
+}
+
 // Fp2 squaring kernel: c0 = (a0 + a1)(a0 - a1), c1 = (2 a0) a1 with one reduction each; inputs with A <= 2
 template <class C, class T> GS_HD void fp2sqr28_generic(T* r0, T* r1, const T* a0, const T* a1) {
   constexpr int L = C::L;
