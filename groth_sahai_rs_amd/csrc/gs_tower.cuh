@@ -317,12 +317,13 @@ GS_ML void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const 
   // the 78 L^2 of the Karatsuba form below, and none of its ~3 500 additions, carry rounds and copies around them.
   const Fp2<C> a0 = f.c0.c0, a1 = f.c0.c1, a2 = f.c0.c2, b0 = f.c1.c0, b1 = f.c1.c1, b2 = f.c1.c2;
   const Fp2<C> xa2 = norm(mul_xi(a2)), xb1 = norm(mul_xi(b1)), xb2 = norm(mul_xi(b2));
+  // (the line coefficients keep their operand slots through all six calls: only the f-side registers change)
   f.c0.c0 = dot3(a0, l0, xa2, l1, xb1, l4);
-  f.c0.c1 = dot3(a0, l1, a1, l0, xb2, l4);
-  f.c0.c2 = dot3(a1, l1, a2, l0, b0, l4);
+  f.c0.c1 = dot3(a1, l0, a0, l1, xb2, l4);
+  f.c0.c2 = dot3(a2, l0, a1, l1, b0, l4);
   f.c1.c0 = dot3(b0, l0, xb2, l1, xa2, l4);
-  f.c1.c1 = dot3(b0, l1, b1, l0, a0, l4);
-  f.c1.c2 = dot3(b1, l1, b2, l0, a1, l4);
+  f.c1.c1 = dot3(b1, l0, b0, l1, a0, l4);
+  f.c1.c2 = dot3(b2, l0, b1, l1, a1, l4);
   return;
 #endif
   Fp6<C> aa, bb, s, t;
@@ -343,12 +344,12 @@ GS_ML void f12_mul_by_034(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l3, const 
   //   c0' = A l0 + v B (l3 + l4 v),  c1' = A (l3 + l4 v) + B l0
   const Fp2<C> a0 = f.c0.c0, a1 = f.c0.c1, a2 = f.c0.c2, b0 = f.c1.c0, b1 = f.c1.c1, b2 = f.c1.c2;
   const Fp2<C> xa2 = norm(mul_xi(a2)), xb1 = norm(mul_xi(b1)), xb2 = norm(mul_xi(b2));
-  f.c0.c0 = dot3(a0, l0, xb1, l4, xb2, l3);
+  f.c0.c0 = dot3(a0, l0, xb2, l3, xb1, l4);
   f.c0.c1 = dot3(a1, l0, b0, l3, xb2, l4);
-  f.c0.c2 = dot3(a2, l0, b0, l4, b1, l3);
-  f.c1.c0 = dot3(a0, l3, xa2, l4, b0, l0);
-  f.c1.c1 = dot3(a0, l4, a1, l3, b1, l0);
-  f.c1.c2 = dot3(a1, l4, a2, l3, b2, l0);
+  f.c0.c2 = dot3(a2, l0, b1, l3, b0, l4);
+  f.c1.c0 = dot3(b0, l0, a0, l3, xa2, l4);
+  f.c1.c1 = dot3(b1, l0, a1, l3, a0, l4);
+  f.c1.c2 = dot3(b2, l0, a2, l3, a1, l4);
   return;
 #endif
   Fp6<C> aa, bb, s, t;
