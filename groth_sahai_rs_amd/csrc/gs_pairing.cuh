@@ -254,7 +254,7 @@ GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0out, Fp12<C>& f1out, const Aff<Fq<C
   // (f0 / f1 stay behind the references: as locals the allocator turns their 336 dwords into one-dword spills and the
   // twin kernel goes from 194 to 228 ms at 2^16; the 16-byte loads and stores through the pointers are the cheaper
   // register file extension)
-  Fp12<C>&f0 = f0out, &f1 = f1out;
+  Fp12<C>&f0 = f0out, &f1 = f1out;  // (one of the two as a local: 178.5 vs 176.4 ms)
   f12_one(f0);
   f12_one(f1);
   bool any = false;
