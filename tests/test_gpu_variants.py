@@ -79,3 +79,20 @@ def test_forced_shapes_wide_statement(cname, cid):
     o = SHAPES["twin6_straus8x2w5_lane"]
     run_batch(cid, cname, 0, 40, 8, 3, range(40), opts=o, expect=expected_kernels(0, 8, 3, o) + ["k_var_multi8w5x2.vg1"],
               seed=9200)
+
+
+def test_option_values_are_validated():
+    """gs_set_option rejects unknown keys and out-of-range values (GS_ERR_ARG) and leaves the context usable."""
+    import groth_sahai_rs_amd as gs
+
+    eng = gs.Engine(0, 0)
+    try:
+        for key, bad in (("no_such_option", 1), ("miller_ch", 13), ("miller_twin", 2), ("var_tm", 9), ("var_mo", 3),
+                         ("var_w", 6), ("red_k", 3), ("var_ws_lanes", 100), ("coop_fe", 3)):
+            with pytest.raises(gs.GsError):
+                eng.set_option(key, bad)
+        for key, good in (("miller_ch", 12), ("var_mo", 4), ("var_w", 5), ("red_k", 4), ("var_ws_lanes", 128),
+                          ("miller_ch", 0), ("var_mo", 0), ("var_w", 0), ("red_k", 0), ("var_ws_lanes", 0)):
+            eng.set_option(key, good)
+    finally:
+        eng.close()
