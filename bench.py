@@ -459,6 +459,7 @@ def main():
                 rf = r.get("roofline") or {}
                 also[tag] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": st, "workload": r["workload"],
                              "dominant_kernel": rf.get("kernel"), "alu_frac": (rf.get("alu") or {}).get("frac"),
+                             "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
                              "kernels_ms": rf.get("kernels_ms")}
             res["also"] = also
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
