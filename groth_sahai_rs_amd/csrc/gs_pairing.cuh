@@ -98,9 +98,12 @@ template <class C> struct LineAcc {
     Fp2<C> cx = mul_fp(l.lx, p.x), cy = mul_fp(l.ly, p.y);
 #if defined(GS_LINES2_ALL)
     constexpr bool pair_lines = true;
+#elif defined(GS_LINES2_NONE)
+    constexpr bool pair_lines = false;
 #else
     constexpr bool pair_lines = C::IS_BN;
 #endif
+    // (round 2, with the dot-product form of the sparse product: BN254 paired 130.4 ms, unpaired 130.9 ms at 2^16)
     if (!pair_lines) {  // measured on gfx950: pairing is a wash on BLS12-381 (the sparse product is the more
       if (C::TWIST_M)  // register-friendly one) and takes 8 % off k_miller on BN254: lines are paired there only
         f12_mul_by_014(f, l.l0, cx, cy);
