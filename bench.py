@@ -126,6 +126,9 @@ def cpu_latency_split(ref, reps=3):
 # measured v_mad_u64_u32 issue peak of the chip (tools/ubench.hip, profiles/r1/ubench_valu.txt: 4.34 cycles per
 # wave-instruction per SIMD at the 2.4 GHz the runtime reports, 1024 SIMDs x 64 lanes) in G lane-mads/s
 VALU_MAD_PEAK_G = 1024 * 64 * 2.4e9 / 4.34 / 1e9
+# the same pipe at the clock these kernels actually run at (2.07 GHz under this load: profiles/r1/ubench_valu.txt,
+# DESIGN.md 4.1): what "executed_mad_frac" is priced against
+VALU_MAD_PEAK_AT_CLOCK_G = 1024 * 64 * 2.07e9 / 4.34 / 1e9
 
 
 def latest_profile(name):
@@ -144,37 +147,45 @@ def alu_roofline(work, ms, curve_id, dominant):
         cnt = json.load(open(latest_profile("fq_mul_counts.json")))["bls12_381" if curve_id == 0 else "bn254"]
     except Exception as ex:  # the counts are a committed measurement artefact; without them report nothing
         return {"error": "fq_mul_counts.json unavailable: %s" % ex}
-    muls = {}
-    partials = cells = 0
-    for name, (lanes, items) in work.items():
-        g = "g2" if name.endswith("g2") else "g1"
-        k = name.split(".")[0]
-        if k == "k_fix":
-            m = items * 16 * (65535.0 / 65536.0) * cnt[g + "_madd"]  # 16-bit windows
-        elif k == "k_var":
-            m = lanes * cnt[g + "_smul"]
-        elif k.startswith("k_var_multi"):  # k_var_multi<4|8>[w5][x<outputs per table build>]
-            m = items * cnt["%s_straus%s_per_term" % (g, k[len("k_var_multi"):])]
-        elif k == "k_red":
-            m = max(items - 2 * lanes, 0) * cnt[g + "_add"] + lanes * cnt[g + "_red_tail"]
-        elif name == "k_miller.twin":
-            m = lanes * cnt["miller2_per_lane"] + items * cnt["miller2_per_triple"]
-            partials += 2 * lanes
-        elif k == "k_miller":
-            m = lanes * cnt["miller_per_lane"] + items * cnt["miller_per_pair"]
-            partials += lanes
-        elif name == "k_final":
-            m = lanes * cnt["final_exp"]
-            cells += lanes
-        elif name == "k_final.coop":
-            m = lanes * cnt["final_exp_coop_lane"]
-            cells += lanes // 3
-        else:
-            continue
-        muls[name] = m
-    for name in ("k_final", "k_final.coop"):  # products of the Miller partials of each cell
-        if name in muls and partials > cells:
-            muls[name] += (partials - cells) * cnt["f12_mul"] * (3 if name.endswith("coop") else 1)
+    def per_kernel(cnt):
+        """{kernel: count} for a per-primitive table (Fq multiplications, or executed multiply-adds)"""
+        muls = {}
+        partials = cells = 0
+        for name, (lanes, items) in work.items():
+            g = "g2" if name.endswith("g2") else "g1"
+            k = name.split(".")[0]
+            if k == "k_fix":
+                m = items * 16 * (65535.0 / 65536.0) * cnt[g + "_madd"]  # 16-bit windows
+            elif k == "k_var":
+                m = lanes * cnt[g + "_smul"]
+            elif k.startswith("k_var_multi"):  # k_var_multi<4|8>[w5][x<outputs per table build>]
+                m = items * cnt["%s_straus%s_per_term" % (g, k[len("k_var_multi"):])]
+            elif k == "k_red":
+                m = max(items - 2 * lanes, 0) * cnt[g + "_add"] + lanes * cnt[g + "_red_tail"]
+            elif name == "k_miller.twin":
+                m = lanes * cnt["miller2_per_lane"] + items * cnt["miller2_per_triple"]
+                partials += 2 * lanes
+            elif name in ("k_miller.pair", "k_miller.pairdpp"):  # the twin lane's work on two lanes of one accumulator
+                m = (lanes // 2) * cnt["miller2_per_lane"] + items * cnt["miller2_per_triple"]
+                partials += lanes
+            elif k == "k_miller":
+                m = lanes * cnt["miller_per_lane"] + items * cnt["miller_per_pair"]
+                partials += lanes
+            elif name == "k_final":
+                m = lanes * cnt["final_exp"]
+                cells += lanes
+            elif name == "k_final.coop":
+                m = lanes * cnt["final_exp_coop_lane"]
+                cells += lanes // 3
+            else:
+                continue
+            muls[name] = m
+        for name in ("k_final", "k_final.coop"):  # products of the Miller partials of each cell
+            if name in muls and partials > cells:
+                muls[name] += (partials - cells) * cnt["f12_mul"] * (3 if name.endswith("coop") else 1)
+        return muls
+
+    muls = per_kernel(cnt)
     total = sum(muls.values())
     step_s = sum(ms.values()) / 1e3
     mads = cnt["mads_per_fq_mul"]
@@ -183,9 +194,31 @@ def alu_roofline(work, ms, curve_id, dominant):
         a = muls[dominant] * mads / (ms[dominant] / 1e3) / 1e9
         dom = {"kernel": dominant, "achieved": a, "frac": a / VALU_MAD_PEAK_G}
     a = total * mads / step_s / 1e9
-    return {"bound": "valu (v_mad_u64_u32 issue)", "achieved": a, "peak": VALU_MAD_PEAK_G, "unit": "G mad/s",
-            "frac": a / VALU_MAD_PEAK_G, "fq_muls_per_step": total, "mads_per_fq_mul": mads, "dominant": dom,
-            "fq_muls_by_kernel": {k: round(v) for k, v in muls.items()}}
+    out = {"bound": "valu (v_mad_u64_u32 issue)", "achieved": a, "peak": VALU_MAD_PEAK_G, "unit": "G mad/s",
+           "frac": a / VALU_MAD_PEAK_G, "fq_muls_per_step": total, "mads_per_fq_mul": mads, "dominant": dom,
+           "fq_muls_by_kernel": {k: round(v) for k, v in muls.items()}}
+    # ---- the stricter readings.  `frac` above credits every Fq multiplication with the 2 L^2
+    # multiply-adds of the radix-2^28 product at the nominal 2.4 GHz.
+    #   executed_mad_frac      multiply-add instructions the kernels EXECUTE for this work (static counts of the
+    #                          generated multiplier kernels x calls, from the CPU twin's second counter: a squaring is
+    #                          L (L + 1) / 2 + L^2, not 2 L^2) against the same pipe at the clock the kernels run at
+    #   min_mads_per_fq_mul    what a saturated 32-bit-limb product would need (12 x 12 x 2 = 288 for BLS12-381):
+    #                          frac_vs_min_mads prices the USEFUL arithmetic at that floor, at the measured clock
+    ex = cnt.get("executed_mads")
+    if ex:
+        emads = per_kernel(ex)
+        etot = sum(emads.values())
+        out["executed_mads_per_step"] = etot
+        out["peak_at_measured_clock"] = VALU_MAD_PEAK_AT_CLOCK_G
+        out["measured_clock_ghz"] = 2.07
+        out["executed_mad_frac"] = etot / step_s / 1e9 / VALU_MAD_PEAK_AT_CLOCK_G
+        if dominant in emads and ms.get(dominant):
+            out["dominant"]["executed_mad_frac"] = emads[dominant] / (ms[dominant] / 1e3) / 1e9 / VALU_MAD_PEAK_AT_CLOCK_G
+    mn = cnt.get("min_mads_per_fq_mul")
+    if mn:
+        out["min_mads_per_fq_mul"] = mn
+        out["frac_vs_min_mads"] = total * mn / step_s / 1e9 / VALU_MAD_PEAK_AT_CLOCK_G
+    return out
 
 
 def config_tag(log2n, curve, ty, mixed, mode):
@@ -206,8 +239,12 @@ def pmc_traffic(tag, kernel_name):
     except Exception:
         return None, None
     base = kernel_name.split(".")[0]
+    if kernel_name.startswith("k_miller.pair"):
+        base, flag = "k_miller_pair", kernel_name.endswith("dpp")
+    else:
+        flag = kernel_name.endswith(".twin")
     for k, v in tj.items():
-        if base + "<" in k and ("true" in k) == kernel_name.endswith(".twin"):
+        if base + "<" in k and ("true" in k) == flag:
             return v.get("hbm_bytes_per_launch_corrected"), os.path.relpath(p, ROOT)
     return None, None
 
@@ -257,7 +294,7 @@ class Bench:
         eng = self.engine(curve)
         N = 1 << log2n
         rank, world, dist = self.rank, self.world, self.dist
-        if mixed:  # one CRS, three sub-batches (the engine runs one type/shape per call)
+        if mixed:  # one CRS, three sub-batches of different types, proved and verified by ONE mixed call each
             wls = [Workload(eng, ty=0, N=N // 2, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev)]
             for t in (1, 2):
                 wls.append(Workload(eng, ty=t, N=N // 4, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev))
@@ -265,12 +302,22 @@ class Bench:
         else:
             wls = [Workload(eng, ty=ty, N=N, m=m, n=n, seed=20241220 + seed_off + rank, device=self.dev)]
 
+        pparts = [dict(ty=w.ty, N=w.N, m=w.m, n=w.n, X=w.X, Y=w.Y, A=w.A, B=w.B, Gamma=w.Gamma, R=w.R, S=w.S, T=w.T,
+                       xcoms=w.xcoms, ycoms=w.ycoms, pi=w.pi, theta=w.theta) for w in wls]
+        vparts = [dict(ty=w.ty, N=w.N, m=w.m, n=w.n, A=w.A, B=w.B, Gamma=w.Gamma, target=w.target, xcoms=w.xcoms,
+                       ycoms=w.ycoms, pi=w.pi, theta=w.theta, ok=w.ok) for w in wls]
+
         def one_step(collective=True):
-            for w in wls:
-                w.prove()
+            if mixed:  # ONE call: the sub-batches of all types are in flight together (gs_prove_mixed)
+                eng.prove_mixed_dev(pparts)
+            else:
+                wls[0].prove()
             if mode == "exact":
-                for w in wls:
-                    w.verify()
+                if mixed:
+                    eng.verify_mixed_dev(vparts)
+                    eng.sync()  # the verdict tensors are written on the children's streams; the parent joins them
+                else:
+                    wls[0].verify()
                 # rank-combined verdict: number of rejected proofs over all ranks (one 8-byte all-reduce over RCCL)
                 bad = sum((w.ok == 0).sum() for w in wls)
                 if collective and dist is not None:
@@ -318,6 +365,51 @@ class Bench:
             del w
         torch.cuda.empty_cache()
         return res
+
+    def run_hostptr(self, log2n, steps=3, m=4, n=4):
+        """The same PPE workload through the HOST-pointer entry points (gs_prove_batch + gs_verify_batch: what a Rust
+        caller of prove.rs:29-52 / verifier.rs:18-21 holds): pageable numpy arrays in, arrays out, PCIe inside the
+        timed region; next to it the device-resident rate of the same batch on the same box."""
+        import numpy as np
+        import torch
+
+        from groth_sahai_rs_amd.workload import Workload
+
+        eng = self.engine(0)
+        N = 1 << log2n
+        wl = Workload(eng, ty=0, N=N, m=m, n=n, seed=20241220 + 7, device=self.dev, corrupt_every=0)
+        host = lambda t: t.cpu().numpy()
+        X, Y, A, B, G, R, S, T, tgt = [host(getattr(wl, k)) for k in ("X", "Y", "A", "B", "Gamma", "R", "S", "T", "target")]
+
+        def host_step():
+            o = eng.prove_batch(0, N, m, n, X, Y, A, B, G, R, S, T)
+            ok = eng.verify_batch(0, N, m, n, A, B, G, tgt, o["xcoms"], o["ycoms"], o["pi"], o["theta"])
+            return o, ok
+
+        o, ok = host_step()  # warm-up: staging buffers grow here
+        assert ok.all()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o, ok = host_step()
+        dt_h = (time.perf_counter() - t0) / steps
+        wl.step()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        eng.sync()
+        dt_d = (time.perf_counter() - t0) / steps
+        assert ok.all() and wl.ok.cpu().numpy().all() and (o["pi"] == host(wl.pi)).all()
+        nbytes = sum(a.nbytes for a in (X, Y, A, B, G, R, S, T, tgt)) + sum(v.nbytes for v in o.values()) * 2 + \
+            A.nbytes + B.nbytes + G.nbytes + N
+        del wl
+        torch.cuda.empty_cache()
+        return {"value": N / dt_h, "ms_per_step": dt_h * 1e3, "steps": steps,
+                "device_resident_value": N / dt_d, "device_resident_ms_per_step": dt_d * 1e3,
+                "ratio_to_device_resident": dt_d / dt_h, "pcie_bytes_per_step": int(nbytes),
+                "workload": "2^%d PPE m=%d n=%d BLS12-381 through gs_prove_batch + gs_verify_batch (pageable host arrays "
+                            "in and out, pinned staging pipeline inside the library)" % (log2n, m, n)}
 
     def describe(self, log2n, curve, ty, mixed, mode, m, n):
         return "2^%d independent %s equations per GPU, m=%d n=%d, %s, commit_and_prove+verify(%s)" % (
@@ -450,7 +542,8 @@ def main():
         default_cfg = args.curve == 0 and args.type == 0 and not args.mixed and args.mode == "exact"
         if world == 1 and not args.no_also and default_cfg:
             also = {}
-            for tag, kw, st in (("2p12_ppe", dict(log2n=12), 10), ("2p16_mixed", dict(log2n=16, mixed=True), 3),
+            for tag, kw, st in (("2p12_ppe", dict(log2n=12), 10), ("2p12_mixed", dict(log2n=12, mixed=True), 10),
+                                ("2p16_mixed", dict(log2n=16, mixed=True), 3),
                                 ("2p16_mixed_rlc", dict(log2n=16, mixed=True, mode="rlc"), 3),
                                 ("2p16_ppe_bn254", dict(log2n=16, curve=1), 3)):
                 if kw.get("log2n") == args.log2n and len(kw) == 1:
@@ -461,6 +554,8 @@ def main():
                              "dominant_kernel": rf.get("kernel"), "alu_frac": (rf.get("alu") or {}).get("frac"),
                              "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
                              "kernels_ms": rf.get("kernels_ms")}
+            also["2p16_ppe_hostptr"] = b.run_hostptr(16, steps=3)
+            also["2p12_ppe_hostptr"] = b.run_hostptr(12, steps=10)
             res["also"] = also
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             threads, _ = host_cores()

@@ -29,7 +29,24 @@ SYMBOLS = [
     "gs_ctx_create_multi", "gs_multi_destroy", "gs_multi_ndev", "gs_multi_ctx", "gs_multi_last_error",
     "gs_multi_uses_rccl", "gs_multi_shard", "gs_multi_set_crs", "gs_multi_prove_batch", "gs_multi_verify_batch",
     "gs_multi_verify_batch_rlc",
+    "gs_ctx_create_multi_ex", "gs_multi_exchange_note", "gs_multi_sync", "gs_multi_prove_batch_dev",
+    "gs_multi_verify_batch_dev", "gs_multi_verify_batch_rlc_dev", "gs_gt_finalize_dev",
+    "gs_prove_mixed_dev", "gs_prove_mixed", "gs_verify_mixed_dev", "gs_verify_mixed",
 ]
+GS_MIXED_MAX = 8
+GS_MULTI_SHARED_DEVICES = 1
+
+
+class ProvePart(ctypes.Structure):  # gs_prove_part
+    _fields_ = [("equ_type", ctypes.c_int), ("N", ctypes.c_size_t), ("m", ctypes.c_int), ("n", ctypes.c_int)] + \
+               [(k, ctypes.c_void_p) for k in ("X", "Y", "A", "B", "Gamma", "R", "S", "T", "xcoms", "ycoms", "pi", "theta")] + \
+               [("shared_vars", ctypes.c_int)]
+
+
+class VerifyPart(ctypes.Structure):  # gs_verify_part
+    _fields_ = [("equ_type", ctypes.c_int), ("N", ctypes.c_size_t), ("m", ctypes.c_int), ("n", ctypes.c_int)] + \
+               [(k, ctypes.c_void_p) for k in ("A", "B", "Gamma", "target", "xcoms", "ycoms", "pi", "theta", "ok")] + \
+               [("shared_vars", ctypes.c_int)]
 
 
 class GsError(RuntimeError):
@@ -275,6 +292,13 @@ class Engine:
                                                _p(u8(pi)), _p(u8(theta)), _p(rho), _p(acc), _p(ok)))
         return int(ok[0]), acc
 
+    def gt_finalize_dev(self, accs_dev, count):
+        """the same with `count` pairs in device memory (torch tensor)."""
+        _need("gs_gt_finalize_dev", [("accs", accs_dev, count * 2 * self.GT)])
+        ok = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.gs_gt_finalize_dev(self.ctx, ctypes.c_size_t(count), _p(accs_dev), _p(ok)))
+        return int(ok[0])
+
     def gt_finalize(self, accs):
         """accs: bytes of `count` accumulator pairs (host).  FE(prod acc[i][0]) == prod acc[i][1] ?"""
         a = np.ascontiguousarray(accs).view(np.uint8).reshape(-1)
@@ -363,6 +387,78 @@ class Engine:
     def gt_pow_batch_dev(self, n, base, k, out):
         self._chk(self.lib.gs_gt_pow_batch_dev(self.ctx, ctypes.c_size_t(n), _p(base), _p(k), _p(out)))
 
+    # -- mixed batches / mixed-type Statements (gs_prove_mixed, gs_verify_mixed) -----------
+    def _part_sizes(self, ty, N, m, n, shared):
+        sh = self.shape(ty)
+        kx, ky, sx, sy, st = sh["kx"], sh["ky"], sh["sx"], sh["sy"], sh["st"]
+        V = 1 if shared else N
+        return dict(X=V * m * sx, Y=V * n * sy, A=N * n * sx, B=N * m * sy, Gamma=N * m * n * self.FR,
+                    R=V * m * kx * self.FR, S=V * n * ky * self.FR, T=N * ky * kx * self.FR, target=N * st,
+                    xcoms=V * m * self.COM1, ycoms=V * n * self.COM2, pi=N * kx * self.COM2, theta=N * ky * self.COM1,
+                    ok=N)
+
+    def _parts(self, fn, parts, struct, in_keys, out_keys, dev):
+        """parts: dicts with ty, N, m, n, the input arrays and (dev) the output arrays; host outputs are allocated
+        here (xcoms / ycoms only when the part asks with want_coms, default True).  Every length is checked before a
+        pointer crosses the ABI."""
+        if len(parts) > GS_MIXED_MAX:
+            raise GsError(3, "%s: at most %d parts" % (fn, GS_MIXED_MAX))
+        arr = (struct * max(len(parts), 1))()
+        keep, outs = [], []
+        for i, p in enumerate(parts):
+            ty, N, m, n, shared = p["ty"], p["N"], p["m"], p["n"], bool(p.get("shared", False))
+            if not (0 <= ty <= 3) or m < 1 or n < 1:
+                raise GsError(1, "%s: bad equation type or empty variable list" % fn)
+            want = self._part_sizes(ty, N, m, n, shared)
+            a = arr[i]
+            a.equ_type, a.N, a.m, a.n, a.shared_vars = ty, N, m, n, 1 if shared else 0
+            o = {}
+            for k in in_keys:
+                v = p[k]
+                if not dev:
+                    v = np.ascontiguousarray(v).view(np.uint8).reshape(-1)
+                _need(fn, [(k, v, want[k])])
+                keep.append(v)
+                setattr(a, k, _p(v).value)
+            for k in out_keys:
+                if dev:
+                    v = p.get(k)
+                    if v is not None:
+                        _need(fn, [(k, v, want[k])])
+                elif k in ("xcoms", "ycoms") and not p.get("want_coms", True):
+                    v = None
+                else:
+                    v = np.zeros(want[k], dtype=np.uint8)
+                keep.append(v)
+                o[k] = v
+                setattr(a, k, _p(v).value)
+            outs.append(o)
+        return arr, keep, outs
+
+    def prove_mixed(self, parts):
+        """Several sub-batches (any types / shapes) in one call, host arrays.  -> list of dicts of outputs."""
+        arr, keep, outs = self._parts("gs_prove_mixed", parts, ProvePart, ("X", "Y", "A", "B", "Gamma", "R", "S", "T"),
+                                      ("xcoms", "ycoms", "pi", "theta"), False)
+        self._chk(self.lib.gs_prove_mixed(self.ctx, len(parts), arr))
+        return outs
+
+    def verify_mixed(self, parts):
+        arr, keep, outs = self._parts("gs_verify_mixed", parts, VerifyPart,
+                                      ("A", "B", "Gamma", "target", "xcoms", "ycoms", "pi", "theta"), ("ok",), False)
+        self._chk(self.lib.gs_verify_mixed(self.ctx, len(parts), arr))
+        return [o["ok"] for o in outs]
+
+    def prove_mixed_dev(self, parts):
+        """Device tensors in the part dicts (outputs included); asynchronous on the context's stream."""
+        arr, keep, _ = self._parts("gs_prove_mixed_dev", parts, ProvePart, ("X", "Y", "A", "B", "Gamma", "R", "S", "T"),
+                                   ("xcoms", "ycoms", "pi", "theta"), True)
+        self._chk(self.lib.gs_prove_mixed_dev(self.ctx, len(parts), arr))
+
+    def verify_mixed_dev(self, parts):
+        arr, keep, _ = self._parts("gs_verify_mixed_dev", parts, VerifyPart,
+                                   ("A", "B", "Gamma", "target", "xcoms", "ycoms", "pi", "theta"), ("ok",), True)
+        self._chk(self.lib.gs_verify_mixed_dev(self.ctx, len(parts), arr))
+
     # -- wire format (ark-serialize byte strings <-> boundary arrays) -------------------
     def wire_sizes(self):
         out = (ctypes.c_size_t * 6)()
@@ -443,15 +539,19 @@ class MultiEngine:
     """gs_ctx_create_multi: the devices of one node behind one handle.  Host arrays in, host arrays out; the batch is
     cut into contiguous equation blocks, one per device (include/gs_amd.h, multi-GPU section)."""
 
-    def __init__(self, curve=CURVE_BLS12_381, devices=(0,)):
+    def __init__(self, curve=CURVE_BLS12_381, devices=(0,), shared_devices=False):
+        """shared_devices=True (GS_MULTI_SHARED_DEVICES) lets several shards name the same ordinal: the ndev > 1 split
+        on a one-GPU box."""
         self.lib = load_library()
         self.lib.gs_multi_last_error.restype = ctypes.c_char_p
+        self.lib.gs_multi_exchange_note.restype = ctypes.c_char_p
         self.lib.gs_multi_ctx.restype = ctypes.c_void_p
         self.curve = curve
         self.devices = list(devices)
         arr = (ctypes.c_int * len(self.devices))(*self.devices)
         self.h = ctypes.c_void_p()
-        rc = self.lib.gs_ctx_create_multi(curve, arr, len(self.devices), ctypes.byref(self.h))
+        rc = self.lib.gs_ctx_create_multi_ex(curve, arr, len(self.devices),
+                                             GS_MULTI_SHARED_DEVICES if shared_devices else 0, ctypes.byref(self.h))
         if rc != 0:
             raise GsError(rc, "gs_ctx_create_multi failed (no usable HIP device? there is no CPU fallback)")
         sz = (ctypes.c_size_t * 6)()
@@ -491,6 +591,53 @@ class MultiEngine:
 
     def uses_rccl(self):
         return bool(self.lib.gs_multi_uses_rccl(self.h))
+
+    def exchange_note(self):
+        return (self.lib.gs_multi_exchange_note(self.h) or b"").decode()
+
+    def sync(self):
+        self._chk(self.lib.gs_multi_sync(self.h))
+
+    # -- device-resident shards: lists of ndev torch tensors (entry i on devices[i], shard i's block) -----------------
+    def _pp(self, lst):
+        if lst is None:
+            return None
+        assert len(lst) == len(self.devices)
+        return (ctypes.c_void_p * len(lst))(*[_p(t).value for t in lst])
+
+    def prove_batch_dev(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, xcoms, ycoms, pi, theta):
+        for i in range(len(self.devices)):
+            lo, hi = self.shard(N, i)
+            pick = lambda l: None if l is None else l[i]
+            if hi > lo:
+                self._check_prove("gs_multi_prove_batch_dev", ty, hi - lo, m, n, X[i], Y[i], A[i], B[i], Gamma[i], R[i],
+                                  S[i], T[i], pick(xcoms), pick(ycoms), pi[i], theta[i])
+        args = [self._pp(a) for a in (X, Y, A, B, Gamma, R, S, T, xcoms, ycoms, pi, theta)]
+        self._chk(self.lib.gs_multi_prove_batch_dev(self.h, ty, ctypes.c_size_t(N), m, n, *args))
+
+    def verify_batch_dev(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, ok):
+        for i in range(len(self.devices)):
+            lo, hi = self.shard(N, i)
+            if hi > lo:
+                self._check_verify("gs_multi_verify_batch_dev", ty, hi - lo, m, n, A[i], B[i], Gamma[i], target[i],
+                                   xcoms[i], ycoms[i], pi[i], theta[i])
+                _need("gs_multi_verify_batch_dev", [("ok", ok[i], hi - lo)])
+        args = [self._pp(a) for a in (A, B, Gamma, target, xcoms, ycoms, pi, theta, ok)]
+        self._chk(self.lib.gs_multi_verify_batch_dev(self.h, ty, ctypes.c_size_t(N), m, n, *args))
+
+    def verify_batch_rlc_dev(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, rho):
+        """rho: list of per-shard uint64 device tensors (4 per equation of the shard's block).  -> (ok_all, pairs)"""
+        for i in range(len(self.devices)):
+            lo, hi = self.shard(N, i)
+            if hi > lo:
+                self._check_verify("gs_multi_verify_batch_rlc_dev", ty, hi - lo, m, n, A[i], B[i], Gamma[i], target[i],
+                                   xcoms[i], ycoms[i], pi[i], theta[i])
+                _need("gs_multi_verify_batch_rlc_dev", [("rho", rho[i], 32 * (hi - lo))])
+        args = [self._pp(a) for a in (A, B, Gamma, target, xcoms, ycoms, pi, theta, rho)]
+        acc = np.zeros(len(self.devices) * 2 * self.GT, dtype=np.uint8)
+        okb = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.gs_multi_verify_batch_rlc_dev(self.h, ty, ctypes.c_size_t(N), m, n, *args, _p(acc), _p(okb)))
+        return int(okb[0]), acc
 
     def set_crs(self, crs):
         crs = np.ascontiguousarray(crs).view(np.uint8).reshape(-1)

@@ -8,12 +8,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <queue>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -77,7 +83,7 @@ struct gs_ctx {
   std::map<std::string, DevBuf> scratch;
   std::map<std::string, PlanEntry> plans;  // task tables by (name, size, content hash); content compared on a hit
   uint64_t plan_clock = 0;
-  std::map<std::string, std::pair<bool, double>> miller_choice;  // planner decisions by (shape, N, overrides)
+  std::map<std::string, std::pair<int, double>> miller_choice;  // planner decisions by (shape, N, overrides)
   // profiling
   bool prof = false;
   std::map<std::string, ProfEntry> prof_map;
@@ -100,6 +106,18 @@ struct gs_ctx {
   int miller_ch = 0, miller_twin = -1;
   int coop_fe = 1;  // 0 never, 1 when one lane per final exponentiation cannot fill the chip, 2 always
   bool line_tables = true;  // pairs whose G2 argument is a CRS element read precomputed Miller lines
+  // host-pointer entry points (HostPipe below): pinned staging, a copy stream, memcpy workers, per-array events
+  struct HostPipe* pipe = nullptr;  // set while a host-pointer call is enqueuing its kernels
+  struct CopyPool* pool = nullptr;
+  hipStream_t copy_stream = nullptr;
+  void* pin = nullptr;
+  size_t pin_cap = 0;
+  hipEvent_t pev[16] = {nullptr};
+  // mixed batches (gs_prove_mixed / gs_verify_mixed): sub-batches run on child contexts (own stream and scratch,
+  // the parent's CRS tables) so that their kernels share the chip
+  std::vector<gs_ctx*> kids;
+  hipEvent_t kid_ev[2] = {nullptr, nullptr};
+  bool own_stream = false;  // a child's stream belongs to it
 };
 
 static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -116,6 +134,12 @@ static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess
   do {                                                             \
     hipError_t e_ = (call);                                        \
     if (e_ != hipSuccess) return fail(ctx, GS_ERR_DEVICE, #call, e_); \
+  } while (0)
+
+#define RC(x)                 \
+  do {                        \
+    int rc_ = (x);            \
+    if (rc_ != GS_OK) return rc_; \
   } while (0)
 
 static int ensure(gs_ctx* c, DevBuf& b, size_t bytes) {
@@ -143,6 +167,219 @@ static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
   return rc;
 }
 
+// ---- external-profiler markers ("tracing") ---------------------------------------------
+// roctxRangePush / Pop around the phases of prove and verify so that `rocprofv3 --marker-trace` segments a step.
+// librocprofiler-sdk-roctx (or the older libroctx64) is bound at run time and only if present; without it the ranges
+// are no-ops.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+      if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
+    if (!h && getenv("GS_ROCTX"))  // not mapped by a profiler: load it only when asked to
+      for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+struct RangeGuard {
+  bool on;
+  explicit RangeGuard(const char* name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~RangeGuard() {
+    if (on) roctx().pop();
+  }
+};
+
+// ---- host-pointer pipeline ---------------------------------------------------------------------------------------
+// What a drop-in caller hands over are host slices (prove.rs:29-52, verifier.rs:18-21).  Pageable hipMemcpy on the
+// compute stream cost 15 % of a 2^16 step (profiles/r2/host_path_rate.txt).  The un-suffixed entry points now
+//   1. copy every input array into a grow-only PINNED staging buffer with a few memcpy worker threads (CopyPool),
+//      arrays in the order the kernels need them;
+//   2. enqueue the H2D of an array on a separate copy stream as soon as its staging copy is complete, with one event
+//      per array;
+//   3. let the engine wait for exactly the arrays the next kernels read (need(): scalars before the preparation
+//      kernel, the G1 arguments before the G1 side, the G2 arguments before the G2 side / the Miller loop), so that the
+//      upload of the later arrays runs under the kernels of the earlier ones;
+//   4. bring the outputs back array by array (D2H into pinned memory, then the workers copy into the caller's
+//      buffers while the next array is in flight).
+// Equation-chunking the kernels instead would cost more than it hides: the lane shapes want whole batches (2^12
+// equations run at 0.6 of the 2^16 rate).
+struct CopyPool {
+  struct Job {
+    void* dst;
+    const void* src;
+    size_t n;
+    std::atomic<int>* left;
+  };
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Job> q;
+  bool stop = false;
+  explicit CopyPool(int nthreads) {
+    for (int i = 0; i < nthreads; i++)
+      th.emplace_back([this] {
+        for (;;) {
+          Job j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [this] { return stop || !q.empty(); });
+            if (q.empty()) return;
+            j = q.front();
+            q.pop_front();
+          }
+          memcpy(j.dst, j.src, j.n);
+          j.left->fetch_sub(1, std::memory_order_release);
+        }
+      });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+  // copy [src, src + n) to dst in pieces; *left counts the pieces still to do
+  void submit(void* dst, const void* src, size_t n, std::atomic<int>* left) {
+    const size_t piece = (size_t)2 << 20;
+    size_t np = (n + piece - 1) / piece;
+    left->fetch_add((int)np, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < np; i++) {
+        size_t o = i * piece;
+        q.push_back(Job{(uint8_t*)dst + o, (const uint8_t*)src + o, std::min(piece, n - o), left});
+      }
+    }
+    cv.notify_all();
+  }
+  static void wait(std::atomic<int>* left) {
+    while (left->load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  }
+};
+
+struct HostPipe {
+  struct Arr {
+    const void* hin = nullptr;
+    void* hout = nullptr;
+    void* d = nullptr;
+    size_t bytes = 0, off = 0;
+    std::atomic<int> left{0};
+    bool enq = false;
+  };
+  gs_ctx* c;
+  Arr arr[16];
+  int n = 0;
+  bool begun = false;
+  explicit HostPipe(gs_ctx* ctx) : c(ctx) {}
+  ~HostPipe() {
+    for (int i = 0; i < n; i++) CopyPool::wait(&arr[i].left);  // no worker may still touch the caller's memory
+    if (c->pipe == this) c->pipe = nullptr;
+  }
+  // declare array `i` (slots are fixed per entry point: the need() masks name them); null / empty arrays stay absent
+  int in(int i, const void* h, size_t bytes) {
+    if (h && bytes) arr[i].hin = h, arr[i].bytes = bytes;
+    n = std::max(n, i + 1);
+    return GS_OK;
+  }
+  int out(int i, void* h, size_t bytes) {
+    if (h && bytes) arr[i].hout = h, arr[i].bytes = bytes;
+    n = std::max(n, i + 1);
+    return GS_OK;
+  }
+  void* dev(int i) const { return arr[i].d; }
+  // device slots, pinned staging, workers; then the staging copies start, inputs in the order `order` lists them
+  int begin(const int* order, int norder) {
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < n; i++)
+      if (!c->pev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->pev[i], hipEventDisableTiming));
+    if (!c->pool) {
+      int nt = 4;
+      if (const char* e = getenv("GS_COPY_THREADS")) nt = std::max(1, std::min(32, atoi(e)));
+      c->pool = new CopyPool(nt);
+    }
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+      if (!arr[i].bytes) continue;
+      char name[32];
+      snprintf(name, sizeof name, "stage.%d", i);
+      RC(scratch(c, name, arr[i].bytes, &arr[i].d));
+      arr[i].off = total;
+      total += (arr[i].bytes + 255) & ~(size_t)255;
+    }
+    if (total > c->pin_cap) {
+      if (c->pin) hipHostFree(c->pin);
+      c->pin = nullptr;
+      c->pin_cap = 0;
+      hipError_t e = hipHostMalloc(&c->pin, total, hipHostMallocDefault);
+      if (e != hipSuccess) return fail(c, GS_ERR_ALLOC, "hipHostMalloc (pinned staging)", e);
+      c->pin_cap = total;
+    }
+    for (int k = 0; k < norder; k++) {
+      Arr& a = arr[order[k]];
+      if (a.hin) c->pool->submit((uint8_t*)c->pin + a.off, a.hin, a.bytes, &a.left);
+    }
+    begun = true;
+    c->pipe = this;
+    return GS_OK;
+  }
+  // the kernels about to be enqueued read the input arrays in `mask`: their uploads go out (if they have not yet)
+  // and the target stream waits for them
+  int need(unsigned mask) {
+    hipStream_t tgt = c->cur ? c->cur : c->stream;
+    for (int i = 0; i < n; i++) {
+      Arr& a = arr[i];
+      if (!((mask >> i) & 1) || !a.hin) continue;
+      if (!a.enq) {
+        CopyPool::wait(&a.left);
+        HIPCHK(c, hipMemcpyAsync(a.d, (uint8_t*)c->pin + a.off, a.bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->pev[i], c->copy_stream));
+        a.enq = true;
+      }
+      HIPCHK(c, hipStreamWaitEvent(tgt, c->pev[i], 0));
+    }
+    return GS_OK;
+  }
+  // outputs: D2H per array behind the kernels, each copied on to the caller's buffer while the next one is in flight
+  int finish() {
+    c->pipe = nullptr;
+    for (int i = 0; i < n; i++) {
+      Arr& a = arr[i];
+      if (!a.hout) continue;
+      HIPCHK(c, hipMemcpyAsync((uint8_t*)c->pin + a.off, a.d, a.bytes, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipEventRecord(c->pev[i], c->stream));
+    }
+    for (int i = 0; i < n; i++) {
+      Arr& a = arr[i];
+      if (!a.hout) continue;
+      HIPCHK(c, hipEventSynchronize(c->pev[i]));
+      c->pool->submit(a.hout, (uint8_t*)c->pin + a.off, a.bytes, &a.left);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) CopyPool::wait(&arr[i].left);
+    return GS_OK;
+  }
+};
+static inline int need(gs_ctx* c, unsigned mask) { return c->pipe ? c->pipe->need(mask) : GS_OK; }
+// array slots of the host-pointer entry points
+enum { PI_X = 0, PI_Y, PI_A, PI_B, PI_G, PI_R, PI_S, PI_T, PO_XC, PO_YC, PO_PI, PO_TH };           // prove
+enum { VI_A = 0, VI_B, VI_G, VI_TG, VI_XC, VI_YC, VI_PI, VI_TH, VO_OK };                            // verify
+#define BIT(i) (1u << (i))
+
 // ---- Miller-lane planning --------------------------------------------------------------------------
 // A Miller lane carries up to MILLER_CH (P, Q) pairs (twin: (Q, P0, P1) triples with two accumulators) and squares its
 // own accumulator every iteration, so longer lanes do less total work but a small batch needs many short ones to fill
@@ -152,6 +389,10 @@ static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
 struct MCost {
   double base, var, fix;
 };
+// whether the planner may pick the lane-pair form of the twin loop on its own (measured per round: DESIGN.md section 4.2)
+#ifndef GS_PLAN_PAIR
+#define GS_PLAN_PAIR 1
+#endif
 // (profiles/r2/fq_mul_counts.json: miller*_per_lane, _per_pair / _per_triple, _per_fixed_pair / _per_fixed_triple)
 static inline MCost mcost(int curve, bool twin) {
   if (curve == 0) return twin ? MCost{4536.0, 7356.0, 5848.0} : MCost{2268.0, 4432.0, 2924.0};
@@ -215,14 +456,17 @@ static double fold_cost(double n, double unit) {
   }
   return c + n * unit;
 }
-static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTask>& mt, bool twin) {
-  const MCost mc = mcost(c->curve, twin);
+// `pair`: the twin task list run by k_miller_pair -- two lanes of half the length per (equation, task)
+static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTask>& mt, bool twin, bool pair = false) {
+  MCost mc = mcost(c->curve, twin);
+  if (pair) mc = MCost{mc.base / 2, mc.var / 2, mc.fix / 2};
   // Lanes are task-major: a wave is 64 equations of ONE task and lasts as long as that task's lane.  A launch lasts
   // as long as its longest lane, or -- once it is several rounds of waves -- as long as all lanes together take on the
   // SIMD slots (waves of short tasks do not wait for those of long ones).
   double longest = 0, all = 0;
   // waves per task (below 64 equations a wave holds several tasks: a fraction of a wave each)
-  const double wpt = N >= 64 ? (double)(size_t)((N + 63) / 64) : (double)N / 64.0;
+  const size_t NL = pair ? 2 * N : N;  // lanes per task
+  const double wpt = NL >= 64 ? (double)(size_t)((NL + 63) / 64) : (double)NL / 64.0;
   for (const MillerTask& t : mt) {
     double l = mc.base;
     for (int q = 0; q < t.np; q++) l += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix : mc.var;
@@ -250,7 +494,10 @@ static std::vector<double> miller_budgets(const gs_ctx* c, bool twin) {
   return out;
 }
 
-static const size_t VAR_WS_LANES = (size_t)1 << 19;  // k_var_multi lanes per launch (G2, 8 terms: 14 KB of table each)
+// k_var_multi lanes per launch: their Straus tables live in a per-context workspace of 3.5 .. 28 KB per lane (G2, 8
+// terms, 5-bit windows: 28 KB).  Four rounds of resident waves (simd_slots x 64 lanes each) keep the launch overhead
+// below 1 % and bound the workspace at ~7 GB for the largest lane (2 GB for the 2^16 PPE shapes) whatever the batch.
+static inline size_t var_ws_default(const gs_ctx* c) { return 4 * c->simd_slots * 64; }
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
 template <class K, class... Args>
 static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, Args... args) {
@@ -276,11 +523,6 @@ static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, 
   c->work_hint = 0;
   return GS_OK;
 }
-#define RC(x)                 \
-  do {                        \
-    int rc_ = (x);            \
-    if (rc_ != GS_OK) return rc_; \
-  } while (0)
 
 // ---------------------------------------------------------------------------
 // shape helpers
@@ -340,17 +582,30 @@ template <class T> static int upload(gs_ctx* c, const char* name, const std::vec
     if (it != c->plans.end()) {
       PlanEntry& e = it->second;
       if (e.host.size() != nb || (nb && memcmp(e.host.data(), b, nb) != 0)) continue;  // collision: next salt
+      if (!e.dev.p) {  // (cannot happen since entries are inserted after their upload; never hand out a null table)
+        c->plans.erase(it);
+        continue;
+      }
       e.last_use = ++c->plan_clock;
       *out = (const T*)e.dev.p;
       return GS_OK;
     }
     RC(plan_evict(c));
-    PlanEntry& e = c->plans[key];
+    // the entry goes into the cache only once its device copy exists: a failed allocation or copy must not leave a
+    // key behind that a later call (same shape, e.g. a retry with a smaller batch) would hit with a null table
+    PlanEntry e;
+    RC(ensure(c, e.dev, nb + 16));
+    if (nb) {
+      hipError_t ce = hipMemcpy(e.dev.p, b, nb, hipMemcpyHostToDevice);
+      if (ce != hipSuccess) {
+        hipFree(e.dev.p);
+        return fail(c, GS_ERR_DEVICE, "task table upload", ce);
+      }
+    }
     e.host.assign(b, b + nb);
     e.last_use = ++c->plan_clock;
-    RC(ensure(c, e.dev, nb + 16));
-    if (nb) HIPCHK(c, hipMemcpy(e.dev.p, b, nb, hipMemcpyHostToDevice));
     *out = (const T*)e.dev.p;
+    c->plans.emplace(key, std::move(e));
     return GS_OK;
   }
 }
@@ -709,7 +964,7 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     // the lanes' Straus tables: lane-contiguous global workspace (see jac_msm_straus_at), at most VAR_WS_LANES lanes
     // of it; a larger batch goes in several launches over the same workspace
     const int tmax = sp.tm <= 4 ? 4 : 8;
-    const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes : VAR_WS_LANES);
+    const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes : var_ws_default(c));
     void* tabws;
     RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * sizeof(Aff<F>), &tabws));
     // kernel name: k_var_multi<TMAX>[w5][x<outputs per lane>]
@@ -868,6 +1123,10 @@ template <class C> struct Impl {
     PoolMap pm = prove_pool(m, n, kx, ky);
     void* pool;
     RC(scratch(c, "prove.pool", N * pm.total * sizeof(S), &pool));
+    RangeGuard rg_all("gs.prove");
+    // (host-pointer calls: the scalars first; group-valued variables and constants are not read before their side)
+    RC(need(c, BIT(PI_G) | BIT(PI_R) | BIT(PI_S) | BIT(PI_T) | (xg ? 0u : BIT(PI_X) | BIT(PI_A)) |
+                   (yg ? 0u : BIT(PI_Y) | BIT(PI_B))));
     if (wide_prep(m, n)) {  // large arity: one lane per output scalar
       int W = m * kx + n * ky + ky * kx + m + n + kx * n + ky * m;
       RC(launch(c, "k_prep_prove.a", k_prep_prove_wide_a<C>, N * (size_t)W, 64, N * (size_t)W, W, m, n, kx, ky,
@@ -918,6 +1177,8 @@ template <class C> struct Impl {
       outs.stride[0] = (uint32_t)(m * Z::COM1);
       outs.base[1] = (uint8_t*)theta;
       outs.stride[1] = (uint32_t)(ky * Z::COM1);
+      RangeGuard rg("gs.prove.g1");
+      RC(need(c, BIT(PI_X) | BIT(PI_A)));
       RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs,
                           ov ? c->side[1] : nullptr, c->sev[1], c->sev[2], pair_reds ? &red1 : nullptr)));
     }
@@ -941,6 +1202,8 @@ template <class C> struct Impl {
       outs.base[1] = (uint8_t*)pi;
       outs.stride[1] = (uint32_t)(kx * Z::COM2);
       if (ov) c->cur = c->side[0];  // the whole G2 side runs beside the G1 side
+      RangeGuard rg("gs.prove.g2");
+      RC(need(c, BIT(PI_Y) | BIT(PI_B)));
       RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tabs->tab16_g2.p, outs,
                           ov ? c->side[2] : nullptr, c->sev[3], c->sev[4], pair_reds ? &red2 : nullptr)));
       if (ov) {
@@ -1118,6 +1381,7 @@ template <class C> struct Impl {
     pm.total = o;
     void* pool;
     RC(scratch(c, "verify.pool", N * pm.total * sizeof(S), &pool));
+    RC(need(c, BIT(VI_G) | (xg ? 0u : BIT(VI_A)) | (yg ? 0u : BIT(VI_B)) | (ty == GS_QUAD ? BIT(VI_TG) : 0u)));
     const bool wide = wide_prep(m, n);
     if (wide)
       RC(launch(c, "k_fr_canonical", k_fr_canonical<C>, N * (size_t)m * n, 64, N * (size_t)m * n, m * n, (const S*)G,
@@ -1125,8 +1389,9 @@ template <class C> struct Impl {
     RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, wide ? nullptr : (const S*)G,
               xg ? nullptr : (const S*)A, yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm,
               (S*)pool));
-    // lane shape for this batch size: single or twin accumulators, lane-cost budget (cost model above)
-    bool twin = false;
+    // lane shape for this batch size: single or twin accumulators (the twin task list on one lane with two
+    // accumulators, or on a pair of lanes with one each), lane-cost budget (cost model above)
+    int mode = 0;  // 0 single, 1 twin, 2 pair (LDS exchange), 3 pair (DPP exchange)
     double budget = 3 * 4621.0;
     {
       // the choice depends on the shape, the batch size and the overrides only: remembered per context
@@ -1134,27 +1399,31 @@ template <class C> struct Impl {
       snprintf(key, sizeof key, "%d.%d.%d.%zu.%d.%d.%d", ty, m, n, N, c->miller_twin, c->miller_ch, (int)c->line_tables);
       auto hit = c->miller_choice.find(key);
       if (hit != c->miller_choice.end()) {
-        twin = hit->second.first;
+        mode = hit->second.first;
         budget = hit->second.second;
       } else {
         double best = -1;
-        for (int tw = 0; tw < 2; tw++) {
-          if (c->miller_twin >= 0 && tw != c->miller_twin) continue;
-          for (double cand : miller_budgets(c, tw != 0)) {
+        for (int md = 0; md < 3; md++) {
+          if (c->miller_twin >= 0 && md != (c->miller_twin == 3 ? 2 : c->miller_twin)) continue;
+          if (c->miller_twin < 0 && md == 2 && !GS_PLAN_PAIR) continue;
+          for (double cand : miller_budgets(c, md != 0)) {
             VerifyPlan tmp;
-            build_verify_miller(tmp, c->curve, ty, m, n, cand, tw != 0, c->line_tables);
-            double cost = miller_cost(c, N, tmp.mt, tw != 0);
+            build_verify_miller(tmp, c->curve, ty, m, n, cand, md != 0, c->line_tables);
+            double cost = miller_cost(c, N, tmp.mt, md != 0, md == 2);
+            if (md == 2) cost *= 0.97;  // measured: the same triples finish 3-4 % sooner with one accumulator per lane
             if (best < 0 || cost < best) {
               best = cost;
-              twin = tw != 0;
+              mode = md;
               budget = cand;
             }
           }
         }
+        if (mode == 2 && c->miller_twin != 2) mode = 3;  // planned: the DPP exchange (166.7 vs 170.0 ms at 2^16)
         if (c->miller_choice.size() > 4096) c->miller_choice.clear();
-        c->miller_choice[key] = std::make_pair(twin, budget);
+        c->miller_choice[key] = std::make_pair(mode, budget);
       }
     }
+    const bool twin = mode != 0;
     build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false, n), c->line_tables);
     // G1-side points
     void* pa;
@@ -1176,9 +1445,13 @@ template <class C> struct Impl {
       memset(&outs, 0, sizeof outs);
       outs.base[0] = (uint8_t*)pa;
       outs.stride[0] = (uint32_t)(vp.npa * Z::COM1);
+      RangeGuard rg("gs.verify.g1");
+      RC(need(c, BIT(VI_XC) | BIT(VI_A) | BIT(VI_TG) * (ty == GS_MSMEG1 ? 1u : 0u)));
       RC((run_side<C, F1>(c, ".vg1", N, vp.g1, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs)));
     }
     // Miller
+    RangeGuard rg_m("gs.verify.miller");
+    RC(need(c, 0xFFu));  // every input array from here on
     const MillerTask* dmt;
     RC(upload(c, "verify.mt", vp.mt, &dmt));
     int ntask = (int)vp.mt.size();
@@ -1213,7 +1486,13 @@ template <class C> struct Impl {
         for (int q = 0; q < t.np; q++) pairs += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix / mc.var : 1.0;
       c->work_hint = (uint64_t)((double)N * pairs);
     }
-    if (twin)
+    if (mode == 2)
+      RC(launch(c, "k_miller.pair", k_miller_pair<C, false>, 2 * N * ntask, 64, 2 * N * ntask, ntask, dmt, parr, qarr,
+                (GT*)mpart, (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
+    else if (mode == 3)
+      RC(launch(c, "k_miller.pairdpp", k_miller_pair<C, true>, 2 * N * ntask, 64, 2 * N * ntask, ntask, dmt, parr, qarr,
+                (GT*)mpart, (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
+    else if (twin)
       RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
                 (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     else
@@ -1228,7 +1507,9 @@ template <class C> struct Impl {
                     uint8_t* ok, bool shared = false) {
     VerifyPlan vp;
     void* mpart;
+    RangeGuard rg_all("gs.verify");
     RC(verify_front(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, vp, &mpart, shared));
+    RangeGuard rg_f("gs.verify.final");
     int ntask = (int)vp.mt.size();
     // large arities: hundreds of Miller partials per cell -- fold runs of K in parallel until k_final's own serial
     // product is short (segmented K-ary tree in GT)
@@ -1483,7 +1764,8 @@ template <class C> struct Impl {
   }
 
   // accs: count boundary-form pairs (host).  ok = FE(prod accs[i][0]) == prod accs[i][1]
-  static int gt_finalize(gs_ctx* c, size_t count, const void* accs_host, uint8_t* ok_host) {
+  // accs: `count` interleaved pairs (f_i, t_i) in boundary form, on the host or (dev) on this context's device
+  static int gt_finalize(gs_ctx* c, size_t count, const void* accs_host, uint8_t* ok_host, bool dev = false) {
     void *raw, *d, *t, *two, *dok, *twob;
     RC(scratch(c, "fin.raw", 2 * count * Z::GT, &raw));
     RC(scratch(c, "fin.in", 2 * count * sizeof(GT), &d));
@@ -1491,15 +1773,21 @@ template <class C> struct Impl {
     RC(scratch(c, "fin.two", 2 * sizeof(GT), &two));
     RC(scratch(c, "fin.twob", 2 * Z::GT, &twob));
     RC(scratch(c, "fin.ok", 16, &dok));
-    // de-interleave on the host: [f0 f1 ...][t0 t1 ...]
-    std::vector<uint8_t> h(2 * count * Z::GT);
+    // de-interleave: [f0 f1 ...][t0 t1 ...]
     const uint8_t* src = (const uint8_t*)accs_host;
-    for (size_t i = 0; i < count; i++) {
-      memcpy(&h[i * Z::GT], src + (2 * i) * Z::GT, Z::GT);
-      memcpy(&h[(count + i) * Z::GT], src + (2 * i + 1) * Z::GT, Z::GT);
+    if (dev) {  // two strided device-to-device copies on the context's stream
+      HIPCHK(c, hipMemcpy2DAsync(raw, Z::GT, src, 2 * Z::GT, Z::GT, count, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpy2DAsync((uint8_t*)raw + count * Z::GT, Z::GT, src + Z::GT, 2 * Z::GT, Z::GT, count,
+                                 hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      std::vector<uint8_t> h(2 * count * Z::GT);
+      for (size_t i = 0; i < count; i++) {
+        memcpy(&h[i * Z::GT], src + (2 * i) * Z::GT, Z::GT);
+        memcpy(&h[(count + i) * Z::GT], src + (2 * i + 1) * Z::GT, Z::GT);
+      }
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpy(raw, h.data(), h.size(), hipMemcpyHostToDevice));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(raw, h.data(), h.size(), hipMemcpyHostToDevice));
     RC(launch(c, "k_gt_import", k_gt_import<C>, 2 * count, 64, 2 * count, (const uint8_t*)raw, (GT*)d));
     RC(gt_product(c, count, (GT*)d, (GT*)t, (uint8_t*)twob));
     RC(gt_product(c, count, (GT*)d + count, (GT*)t, (uint8_t*)twob + Z::GT));
@@ -1514,8 +1802,20 @@ template <class C> struct Impl {
 // ---------------------------------------------------------------------------
 // dispatch helpers
 // ---------------------------------------------------------------------------
+#if defined(GS_ONLY_BLS)
+// experiment builds (tools/build_variant.sh NAME -DGS_ONLY_BLS): half the compile time, BN254 calls fail
+#define DISPATCH(ctx, EXPR) \
+  ((ctx)->curve == GS_CURVE_BLS12_381 ? Impl<Bls12_381>::EXPR : fail(ctx, GS_ERR_ARG, "built with GS_ONLY_BLS"))
+#else
 #define DISPATCH(ctx, EXPR)                                   \
   ((ctx)->curve == GS_CURVE_BLS12_381 ? Impl<Bls12_381>::EXPR : Impl<Bn254>::EXPR)
+#endif
+
+#if defined(GS_ONLY_BLS)
+#define WIRE_DISPATCH(expr_bls, expr_bn) (c->curve == 0 ? (expr_bls) : fail(c, GS_ERR_ARG, "built with GS_ONLY_BLS"))
+#else
+#define WIRE_DISPATCH(expr_bls, expr_bn) (c->curve == 0 ? (expr_bls) : (expr_bn))
+#endif
 
 static size_t sz_fq(int curve) { return curve == 0 ? 4 * Bls12_381::N : 4 * Bn254::N; }
 static const size_t SZ_FR = 32;
@@ -1762,6 +2062,17 @@ void gs_ctx_destroy(gs_ctx* c) {
     if (st) hipStreamSynchronize(st);
   for (auto& kv : c->plans)
     if (kv.second.dev.p) hipFree(kv.second.dev.p);
+  for (gs_ctx* k : c->kids) gs_ctx_destroy(k);
+  c->kids.clear();
+  hipSetDevice(c->device);
+  delete c->pool;
+  if (c->pin) hipHostFree(c->pin);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  for (hipEvent_t ev : c->pev)
+    if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : c->kid_ev)
+    if (ev) hipEventDestroy(ev);
   c->tabs.reset();  // the CRS tables go with their last context
   for (hipStream_t st : c->side)
     if (st) hipStreamDestroy(st);
@@ -1781,7 +2092,8 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
   if (!c || !key) return GS_ERR_ARG;
   std::string k(key);
   if (k == "miller_twin") {
-    if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "miller_twin: -1 (planned), 0, 1");
+    if (value < -1 || value > 3)
+      return fail(c, GS_ERR_ARG, "miller_twin: -1 (planned), 0 single, 1 twin, 2 lane pair (LDS), 3 lane pair (DPP)");
     c->miller_twin = value;
   } else if (k == "miller_ch") {
     if (value < 0 || value > MILLER_CH) return fail(c, GS_ERR_ARG, "miller_ch: 0 (planned) .. capacity of a Miller lane");
@@ -1952,35 +2264,55 @@ int gs_prove_batch_dev(gs_ctx* c, int ty, size_t N, int m, int n, const void* X,
   return DISPATCH(c, prove(c, ty, N, m, n, X, Y, A, B, G, R, S, T, xcoms, ycoms, pi, theta));
 }
 
+// host-pointer prove in three phases so that a mixed call can interleave several sub-batches: stage (the workers start
+// copying), run (kernels enqueued behind per-array upload events), finish (outputs back, stream drained)
+struct ProveArgs {
+  int ty;
+  size_t N;
+  int m, n;
+  const void *X, *Y, *A, *B, *G, *R, *S, *T;
+  void *xcoms, *ycoms, *pi, *theta;
+  bool shared;  // a Statement's part: ONE copy of X, Y, R, S and of the commitments for all N equations
+};
+static int prove_host_stage(gs_ctx* c, const ProveArgs& a, HostPipe& hp) {
+  size_t fq = sz_fq(c->curve), N = a.N;
+  bool xg = x_is_group(a.ty), yg = y_is_group(a.ty);
+  int kx = xg ? 2 : 1, ky = yg ? 2 : 1, m = a.m, n = a.n;
+  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
+  const size_t V = a.shared ? 1 : N;
+  hp.in(PI_X, a.X, V * m * sx);
+  hp.in(PI_Y, a.Y, V * n * sy);
+  hp.in(PI_A, a.A, N * n * sx);
+  hp.in(PI_B, a.B, N * m * sy);
+  hp.in(PI_G, a.G, N * m * n * SZ_FR);
+  hp.in(PI_R, a.R, V * m * kx * SZ_FR);
+  hp.in(PI_S, a.S, V * n * ky * SZ_FR);
+  hp.in(PI_T, a.T, N * ky * kx * SZ_FR);
+  hp.out(PO_XC, a.xcoms, V * m * 4 * fq);
+  hp.out(PO_YC, a.ycoms, V * n * 8 * fq);
+  hp.out(PO_PI, a.pi, N * kx * 8 * fq);
+  hp.out(PO_TH, a.theta, N * ky * 4 * fq);
+  // staging order = the order prove() asks for them (scalars, then the G1 side's arguments, then the G2 side's)
+  static const int order[] = {PI_G, PI_R, PI_S, PI_T, PI_X, PI_A, PI_Y, PI_B};
+  return hp.begin(order, 8);
+}
+static int prove_host_run(gs_ctx* c, const ProveArgs& a, HostPipe& hp) {
+  return (a.shared ? gs_prove_statement_dev : gs_prove_batch_dev)(c, a.ty, a.N, a.m, a.n, hp.dev(PI_X), hp.dev(PI_Y), hp.dev(PI_A), hp.dev(PI_B), hp.dev(PI_G),
+                            hp.dev(PI_R), hp.dev(PI_S), hp.dev(PI_T), hp.dev(PO_XC), hp.dev(PO_YC), hp.dev(PO_PI),
+                            hp.dev(PO_TH));
+}
 int gs_prove_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* X, const void* Y, const void* A,
                    const void* B, const void* G, const void* R, const void* S, const void* T, void* xcoms,
                    void* ycoms, void* pi, void* theta) {
   RC(check_ctx(c, true));
   RC(check_shape(c, ty, m, n));
   if (N == 0) return GS_OK;
-  size_t fq = sz_fq(c->curve);
-  bool xg = x_is_group(ty), yg = y_is_group(ty);
-  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
-  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
-  HostStage st(c);
-  void *dX, *dY, *dA, *dB, *dG, *dR, *dS, *dT, *dxc, *dyc, *dpi, *dth;
-  RC(st.in(X, N * m * sx, &dX));
-  RC(st.in(Y, N * n * sy, &dY));
-  RC(st.in(A, N * n * sx, &dA));
-  RC(st.in(B, N * m * sy, &dB));
-  RC(st.in(G, N * m * n * SZ_FR, &dG));
-  RC(st.in(R, N * m * kx * SZ_FR, &dR));
-  RC(st.in(S, N * n * ky * SZ_FR, &dS));
-  RC(st.in(T, N * ky * kx * SZ_FR, &dT));
-  RC(st.out(xcoms, N * m * 4 * fq, &dxc));
-  RC(st.out(ycoms, N * n * 8 * fq, &dyc));
-  RC(st.out(pi, N * kx * 8 * fq, &dpi));
-  RC(st.out(theta, N * ky * 4 * fq, &dth));
-  RC(gs_prove_batch_dev(c, ty, N, m, n, dX, dY, dA, dB, dG, dR, dS, dT, dxc, dyc, dpi, dth));
-  RC(st.back(xcoms, dxc, N * m * 4 * fq));
-  RC(st.back(ycoms, dyc, N * n * 8 * fq));
-  RC(st.back(pi, dpi, N * kx * 8 * fq));
-  return st.back(theta, dth, N * ky * 4 * fq);
+  if (!X || !Y || !A || !B || !G || !R || !S || !T || !pi || !theta) return fail(c, GS_ERR_ARG, "null pointer");
+  ProveArgs a{ty, N, m, n, X, Y, A, B, G, R, S, T, xcoms, ycoms, pi, theta, false};
+  HostPipe hp(c);
+  RC(prove_host_stage(c, a, hp));
+  RC(prove_host_run(c, a, hp));
+  return hp.finish();
 }
 
 // ---- verify ------------------------------------------------------------------
@@ -1994,30 +2326,245 @@ int gs_verify_batch_dev(gs_ctx* c, int ty, size_t N, int m, int n, const void* A
   return DISPATCH(c, verify(c, ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, ok));
 }
 
+struct VerifyArgs {
+  int ty;
+  size_t N;
+  int m, n;
+  const void *A, *B, *G, *target, *xcoms, *ycoms, *pi, *theta;
+  uint8_t* ok;
+  bool shared;
+};
+static int verify_host_stage(gs_ctx* c, const VerifyArgs& a, HostPipe& hp) {
+  size_t fq = sz_fq(c->curve), N = a.N;
+  int ty = a.ty, m = a.m, n = a.n;
+  bool xg = x_is_group(ty), yg = y_is_group(ty);
+  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
+  size_t st_ = ty == GS_PPE ? 12 * fq : ty == GS_MSMEG1 ? 2 * fq : ty == GS_MSMEG2 ? 4 * fq : SZ_FR;
+  hp.in(VI_A, a.A, N * n * sx);
+  hp.in(VI_B, a.B, N * m * sy);
+  hp.in(VI_G, a.G, N * m * n * SZ_FR);
+  hp.in(VI_TG, a.target, N * st_);
+  hp.in(VI_XC, a.xcoms, (a.shared ? 1 : N) * m * 4 * fq);
+  hp.in(VI_YC, a.ycoms, (a.shared ? 1 : N) * n * 8 * fq);
+  hp.in(VI_PI, a.pi, N * kx * 8 * fq);
+  hp.in(VI_TH, a.theta, N * ky * 4 * fq);
+  hp.out(VO_OK, a.ok, N);
+  // Gamma and the G1-side arguments first (the verifier's Gamma-MSM runs under the upload of the rest)
+  static const int order_g[] = {VI_G, VI_A, VI_XC, VI_TG, VI_B, VI_YC, VI_PI, VI_TH};
+  static const int order_s[] = {VI_G, VI_A, VI_B, VI_TG, VI_XC, VI_YC, VI_PI, VI_TH};
+  return hp.begin(ty == GS_PPE || ty == GS_MSMEG2 ? order_g : order_s, 8);
+}
+static int verify_host_run(gs_ctx* c, const VerifyArgs& a, HostPipe& hp) {
+  return (a.shared ? gs_verify_statement_dev : gs_verify_batch_dev)(c, a.ty, a.N, a.m, a.n, hp.dev(VI_A), hp.dev(VI_B), hp.dev(VI_G), hp.dev(VI_TG),
+                             hp.dev(VI_XC), hp.dev(VI_YC), hp.dev(VI_PI), hp.dev(VI_TH), (uint8_t*)hp.dev(VO_OK));
+}
 int gs_verify_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, const void* B, const void* G,
                     const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
                     uint8_t* ok) {
   RC(check_ctx(c, true));
   RC(check_shape(c, ty, m, n));
   if (N == 0) return GS_OK;
-  size_t fq = sz_fq(c->curve);
-  bool xg = x_is_group(ty), yg = y_is_group(ty);
-  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
-  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
-  size_t st_ = ty == GS_PPE ? 12 * fq : ty == GS_MSMEG1 ? 2 * fq : ty == GS_MSMEG2 ? 4 * fq : SZ_FR;
-  HostStage st(c);
-  void *dA, *dB, *dG, *dt, *dxc, *dyc, *dpi, *dth, *dok;
-  RC(st.in(A, N * n * sx, &dA));
-  RC(st.in(B, N * m * sy, &dB));
-  RC(st.in(G, N * m * n * SZ_FR, &dG));
-  RC(st.in(target, N * st_, &dt));
-  RC(st.in(xcoms, N * m * 4 * fq, &dxc));
-  RC(st.in(ycoms, N * n * 8 * fq, &dyc));
-  RC(st.in(pi, N * kx * 8 * fq, &dpi));
-  RC(st.in(theta, N * ky * 4 * fq, &dth));
-  RC(st.out(ok, N, &dok));
-  RC(gs_verify_batch_dev(c, ty, N, m, n, dA, dB, dG, dt, dxc, dyc, dpi, dth, (uint8_t*)dok));
-  return st.back(ok, dok, N);
+  if (!A || !B || !G || !target || !xcoms || !ycoms || !pi || !theta || !ok) return fail(c, GS_ERR_ARG, "null pointer");
+  VerifyArgs a{ty, N, m, n, A, B, G, target, xcoms, ycoms, pi, theta, ok, false};
+  HostPipe hp(c);
+  RC(verify_host_stage(c, a, hp));
+  RC(verify_host_run(c, a, hp));
+  return hp.finish();
+}
+
+// ---- mixed batches: several sub-batches (any types and shapes) in ONE call ----------------------------------------
+// configs[2] of the baseline is a batch of PPE, MSMEG1 and MSMEG2 equations; the reference's Statement is a list of
+// equations of any type (statement.rs:24-28).  Every sub-batch runs the ordinary engine on a CHILD context -- its own
+// stream, scratch and planner state, the parent's CRS tables -- so the kernels of all sub-batches are in flight together
+// and share the SIMDs: a mixed batch of a few thousand equations fills the chip like a homogeneous one of its total
+// size, where three calls in a row run three under-filled launch chains one after the other.  Ordered on the parent's
+// stream like every other _dev call: the children start behind it and it continues behind them.
+static int kid(gs_ctx* c, int i, gs_ctx** out) {
+  while ((int)c->kids.size() <= i) {
+    gs_ctx* k = nullptr;
+    int rc = gs_ctx_create(c->curve, c->device, &k);
+    if (rc != GS_OK) return fail(c, rc, "child context");
+    if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) {
+      gs_ctx_destroy(k);
+      return fail(c, GS_ERR_DEVICE, "child stream");
+    }
+    k->own_stream = true;
+    c->kids.push_back(k);
+  }
+  gs_ctx* k = c->kids[i];
+  k->tabs = c->tabs;
+  k->have_crs = c->have_crs;
+  k->var_tm = c->var_tm, k->red_k = c->red_k, k->var_ws_lanes = c->var_ws_lanes, k->var_mo = c->var_mo, k->var_w = c->var_w;
+  k->miller_ch = c->miller_ch, k->miller_twin = c->miller_twin, k->coop_fe = c->coop_fe, k->line_tables = c->line_tables;
+  k->overlap = c->overlap && k->side[0] != nullptr;
+  *out = k;
+  return GS_OK;
+}
+// stream plumbing around the children of one mixed call
+static int kids_fork(gs_ctx* c, int nk) {
+  for (int e = 0; e < 2; e++)
+    if (!c->kid_ev[e]) HIPCHK(c, hipEventCreateWithFlags(&c->kid_ev[e], hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->kid_ev[0], c->stream));
+  for (int i = 0; i < nk; i++) HIPCHK(c, hipStreamWaitEvent(c->kids[i]->stream, c->kid_ev[0], 0));
+  return GS_OK;
+}
+static int kids_join(gs_ctx* c, int nk) {
+  for (int i = 0; i < nk; i++) {
+    HIPCHK(c, hipEventRecord(c->kid_ev[1], c->kids[i]->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->kid_ev[1], 0));
+  }
+  return GS_OK;
+}
+static int kid_fail(gs_ctx* c, gs_ctx* k, int rc) {
+  c->err = k->err;
+  return rc;
+}
+// under the library's kernel profile (gs_prof_enable) the sub-batches run one after the other on the parent itself:
+// the profile is per context and times each launch on its own
+static bool mixed_inline(const gs_ctx* c, int nparts) { return c->prof || nparts == 1; }
+
+int gs_prove_mixed_dev(gs_ctx* c, int nparts, const gs_prove_part* p) {
+  RC(check_ctx(c, true));
+  if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_prove_mixed: 0..8 parts");
+  if (nparts == 0) return GS_OK;
+  RangeGuard rg("gs.prove_mixed");
+  if (mixed_inline(c, nparts)) {
+    for (int i = 0; i < nparts; i++)
+      RC((p[i].shared_vars ? gs_prove_statement_dev : gs_prove_batch_dev)(
+          c, p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R, p[i].S, p[i].T,
+          p[i].xcoms, p[i].ycoms, p[i].pi, p[i].theta));
+    return GS_OK;
+  }
+  gs_ctx* k[GS_MIXED_MAX];
+  for (int i = 0; i < nparts; i++) RC(kid(c, i, &k[i]));
+  RC(kids_fork(c, nparts));
+  int rc = GS_OK;
+  for (int i = 0; i < nparts && rc == GS_OK; i++) {
+    rc = (p[i].shared_vars ? gs_prove_statement_dev : gs_prove_batch_dev)(
+        k[i], p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R, p[i].S, p[i].T,
+        p[i].xcoms, p[i].ycoms, p[i].pi, p[i].theta);
+    if (rc != GS_OK) kid_fail(c, k[i], rc);
+  }
+  int jr = kids_join(c, nparts);  // also after a failure: what was enqueued stays ordered before the caller's next work
+  return rc != GS_OK ? rc : jr;
+}
+int gs_verify_mixed_dev(gs_ctx* c, int nparts, const gs_verify_part* p) {
+  RC(check_ctx(c, true));
+  if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_verify_mixed: 0..8 parts");
+  if (nparts == 0) return GS_OK;
+  RangeGuard rg("gs.verify_mixed");
+  if (mixed_inline(c, nparts)) {
+    for (int i = 0; i < nparts; i++)
+      RC((p[i].shared_vars ? gs_verify_statement_dev : gs_verify_batch_dev)(
+          c, p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].A, p[i].B, p[i].Gamma, p[i].target, p[i].xcoms, p[i].ycoms,
+          p[i].pi, p[i].theta, p[i].ok));
+    return GS_OK;
+  }
+  gs_ctx* k[GS_MIXED_MAX];
+  for (int i = 0; i < nparts; i++) RC(kid(c, i, &k[i]));
+  RC(kids_fork(c, nparts));
+  int rc = GS_OK;
+  for (int i = 0; i < nparts && rc == GS_OK; i++) {
+    rc = (p[i].shared_vars ? gs_verify_statement_dev : gs_verify_batch_dev)(
+        k[i], p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].A, p[i].B, p[i].Gamma, p[i].target, p[i].xcoms, p[i].ycoms,
+        p[i].pi, p[i].theta, p[i].ok);
+    if (rc != GS_OK) kid_fail(c, k[i], rc);
+  }
+  int jr = kids_join(c, nparts);
+  return rc != GS_OK ? rc : jr;
+}
+// host pointers: every sub-batch is staged first (the memcpy workers of all children run together), then all kernels
+// are enqueued, then the outputs come back
+int gs_prove_mixed(gs_ctx* c, int nparts, const gs_prove_part* p) {
+  RC(check_ctx(c, true));
+  if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_prove_mixed: 0..8 parts");
+  for (int i = 0; i < nparts; i++) {
+    RC(check_shape(c, p[i].equ_type, p[i].m, p[i].n));
+    if (p[i].N && (!p[i].X || !p[i].Y || !p[i].A || !p[i].B || !p[i].Gamma || !p[i].R || !p[i].S || !p[i].T || !p[i].pi ||
+                   !p[i].theta))
+      return fail(c, GS_ERR_ARG, "null pointer");
+  }
+  RangeGuard rg("gs.prove_mixed");
+  std::vector<std::unique_ptr<HostPipe>> hp;
+  std::vector<gs_ctx*> k;
+  std::vector<ProveArgs> a;
+  const bool inl = mixed_inline(c, nparts);
+  for (int i = 0; i < nparts; i++) {
+    if (p[i].N == 0) continue;
+    gs_ctx* kc = c;
+    if (!inl) RC(kid(c, (int)k.size(), &kc));
+    k.push_back(kc);
+    a.push_back(ProveArgs{p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R,
+                          p[i].S, p[i].T, p[i].xcoms, p[i].ycoms, p[i].pi, p[i].theta, p[i].shared_vars != 0});
+  }
+  if (inl) {  // one after the other on the parent (a context has one pipe)
+    for (size_t i = 0; i < a.size(); i++) {
+      HostPipe h(c);
+      RC(prove_host_stage(c, a[i], h));
+      RC(prove_host_run(c, a[i], h));
+      RC(h.finish());
+    }
+    return GS_OK;
+  }
+  for (size_t i = 0; i < a.size(); i++) {
+    hp.emplace_back(new HostPipe(k[i]));
+    int rc = prove_host_stage(k[i], a[i], *hp[i]);
+    if (rc != GS_OK) return kid_fail(c, k[i], rc);
+  }
+  int rc = GS_OK;
+  for (size_t i = 0; i < a.size() && rc == GS_OK; i++)
+    if ((rc = prove_host_run(k[i], a[i], *hp[i])) != GS_OK) kid_fail(c, k[i], rc);
+  for (size_t i = 0; i < a.size(); i++) {
+    int fr = rc == GS_OK ? hp[i]->finish() : (hipStreamSynchronize(k[i]->stream), GS_OK);
+    if (fr != GS_OK && rc == GS_OK) rc = kid_fail(c, k[i], fr);
+  }
+  return rc;
+}
+int gs_verify_mixed(gs_ctx* c, int nparts, const gs_verify_part* p) {
+  RC(check_ctx(c, true));
+  if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_verify_mixed: 0..8 parts");
+  for (int i = 0; i < nparts; i++) {
+    RC(check_shape(c, p[i].equ_type, p[i].m, p[i].n));
+    if (p[i].N && (!p[i].A || !p[i].B || !p[i].Gamma || !p[i].target || !p[i].xcoms || !p[i].ycoms || !p[i].pi ||
+                   !p[i].theta || !p[i].ok))
+      return fail(c, GS_ERR_ARG, "null pointer");
+  }
+  RangeGuard rg("gs.verify_mixed");
+  std::vector<std::unique_ptr<HostPipe>> hp;
+  std::vector<gs_ctx*> k;
+  std::vector<VerifyArgs> a;
+  const bool inl = mixed_inline(c, nparts);
+  for (int i = 0; i < nparts; i++) {
+    if (p[i].N == 0) continue;
+    gs_ctx* kc = c;
+    if (!inl) RC(kid(c, (int)k.size(), &kc));
+    k.push_back(kc);
+    a.push_back(VerifyArgs{p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].A, p[i].B, p[i].Gamma, p[i].target, p[i].xcoms,
+                           p[i].ycoms, p[i].pi, p[i].theta, p[i].ok, p[i].shared_vars != 0});
+  }
+  if (inl) {
+    for (size_t i = 0; i < a.size(); i++) {
+      HostPipe h(c);
+      RC(verify_host_stage(c, a[i], h));
+      RC(verify_host_run(c, a[i], h));
+      RC(h.finish());
+    }
+    return GS_OK;
+  }
+  for (size_t i = 0; i < a.size(); i++) {
+    hp.emplace_back(new HostPipe(k[i]));
+    int rc = verify_host_stage(k[i], a[i], *hp[i]);
+    if (rc != GS_OK) return kid_fail(c, k[i], rc);
+  }
+  int rc = GS_OK;
+  for (size_t i = 0; i < a.size() && rc == GS_OK; i++)
+    if ((rc = verify_host_run(k[i], a[i], *hp[i])) != GS_OK) kid_fail(c, k[i], rc);
+  for (size_t i = 0; i < a.size(); i++) {
+    int fr = rc == GS_OK ? hp[i]->finish() : (hipStreamSynchronize(k[i]->stream), GS_OK);
+    if (fr != GS_OK && rc == GS_OK) rc = kid_fail(c, k[i], fr);
+  }
+  return rc;
 }
 
 // ---- Statement: E equations of one type over the SAME committed variables (statement.rs:24-28,109) -------------
@@ -2030,6 +2577,7 @@ int gs_prove_statement_dev(gs_ctx* c, int ty, size_t E, int m, int n, const void
   if (!X || !Y || !A || !B || !G || !R || !S || !T || !pi || !theta) return fail(c, GS_ERR_ARG, "null pointer");
   bool xg = x_is_group(ty), yg = y_is_group(ty);
   // the commitments, once (commit.rs:78-100,125-156,178-200,225-256)
+  RC(need(c, BIT(PI_X) | BIT(PI_Y) | BIT(PI_R) | BIT(PI_S)));
   if (xcoms) RC((xg ? gs_commit_g1_dev : gs_commit_fr_b1_dev)(c, (size_t)m, X, R, xcoms));
   if (ycoms) RC((yg ? gs_commit_g2_dev : gs_commit_fr_b2_dev)(c, (size_t)n, Y, S, ycoms));
   return DISPATCH(c, prove(c, ty, E, m, n, X, Y, A, B, G, R, S, T, nullptr, nullptr, pi, theta, true));
@@ -2049,29 +2597,12 @@ int gs_prove_statement(gs_ctx* c, int ty, size_t E, int m, int n, const void* X,
   RC(check_ctx(c, true));
   RC(check_shape(c, ty, m, n));
   if (E == 0) return GS_OK;
-  size_t fq = sz_fq(c->curve);
-  bool xg = x_is_group(ty), yg = y_is_group(ty);
-  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
-  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
-  HostStage st(c);
-  void *dX, *dY, *dA, *dB, *dG, *dR, *dS, *dT, *dxc, *dyc, *dpi, *dth;
-  RC(st.in(X, (size_t)m * sx, &dX));
-  RC(st.in(Y, (size_t)n * sy, &dY));
-  RC(st.in(A, E * n * sx, &dA));
-  RC(st.in(B, E * m * sy, &dB));
-  RC(st.in(G, E * m * n * SZ_FR, &dG));
-  RC(st.in(R, (size_t)m * kx * SZ_FR, &dR));
-  RC(st.in(S, (size_t)n * ky * SZ_FR, &dS));
-  RC(st.in(T, E * ky * kx * SZ_FR, &dT));
-  RC(st.out(xcoms, (size_t)m * 4 * fq, &dxc));
-  RC(st.out(ycoms, (size_t)n * 8 * fq, &dyc));
-  RC(st.out(pi, E * kx * 8 * fq, &dpi));
-  RC(st.out(theta, E * ky * 4 * fq, &dth));
-  RC(gs_prove_statement_dev(c, ty, E, m, n, dX, dY, dA, dB, dG, dR, dS, dT, dxc, dyc, dpi, dth));
-  RC(st.back(xcoms, dxc, (size_t)m * 4 * fq));
-  RC(st.back(ycoms, dyc, (size_t)n * 8 * fq));
-  RC(st.back(pi, dpi, E * kx * 8 * fq));
-  return st.back(theta, dth, E * ky * 4 * fq);
+  if (!X || !Y || !A || !B || !G || !R || !S || !T || !pi || !theta) return fail(c, GS_ERR_ARG, "null pointer");
+  ProveArgs a{ty, E, m, n, X, Y, A, B, G, R, S, T, xcoms, ycoms, pi, theta, true};
+  HostPipe hp(c);
+  RC(prove_host_stage(c, a, hp));
+  RC(prove_host_run(c, a, hp));
+  return hp.finish();
 }
 int gs_verify_statement(gs_ctx* c, int ty, size_t E, int m, int n, const void* A, const void* B, const void* G,
                         const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
@@ -2079,24 +2610,12 @@ int gs_verify_statement(gs_ctx* c, int ty, size_t E, int m, int n, const void* A
   RC(check_ctx(c, true));
   RC(check_shape(c, ty, m, n));
   if (E == 0) return GS_OK;
-  size_t fq = sz_fq(c->curve);
-  bool xg = x_is_group(ty), yg = y_is_group(ty);
-  int kx = xg ? 2 : 1, ky = yg ? 2 : 1;
-  size_t sx = xg ? 2 * fq : SZ_FR, sy = yg ? 4 * fq : SZ_FR;
-  size_t st_ = ty == GS_PPE ? 12 * fq : ty == GS_MSMEG1 ? 2 * fq : ty == GS_MSMEG2 ? 4 * fq : SZ_FR;
-  HostStage st(c);
-  void *dA, *dB, *dG, *dt, *dxc, *dyc, *dpi, *dth, *dok;
-  RC(st.in(A, E * n * sx, &dA));
-  RC(st.in(B, E * m * sy, &dB));
-  RC(st.in(G, E * m * n * SZ_FR, &dG));
-  RC(st.in(target, E * st_, &dt));
-  RC(st.in(xcoms, (size_t)m * 4 * fq, &dxc));
-  RC(st.in(ycoms, (size_t)n * 8 * fq, &dyc));
-  RC(st.in(pi, E * kx * 8 * fq, &dpi));
-  RC(st.in(theta, E * ky * 4 * fq, &dth));
-  RC(st.out(ok, E, &dok));
-  RC(gs_verify_statement_dev(c, ty, E, m, n, dA, dB, dG, dt, dxc, dyc, dpi, dth, (uint8_t*)dok));
-  return st.back(ok, dok, E);
+  if (!A || !B || !G || !target || !xcoms || !ycoms || !pi || !theta || !ok) return fail(c, GS_ERR_ARG, "null pointer");
+  VerifyArgs a{ty, E, m, n, A, B, G, target, xcoms, ycoms, pi, theta, ok, true};
+  HostPipe hp(c);
+  RC(verify_host_stage(c, a, hp));
+  RC(verify_host_run(c, a, hp));
+  return hp.finish();
 }
 
 // ---- helpers / hooks -----------------------------------------------------------
@@ -2198,14 +2717,14 @@ int gs_pairing_sum(gs_ctx* c, int k, const void* x, const void* y, void* out) {
 int gs_mat_left_mul_com1(gs_ctx* c, int rows, int k, const void* lhs, const void* col, void* out) {
   RC(check_ctx(c, false));
   if (rows <= 0 || k <= 0) return GS_OK;  // empty product (data_structures.rs:697-702)
-  if (c->curve == 0) return left_mul_impl<Bls12_381, Fq<Bls12_381>>(c, rows, k, lhs, col, out);
-  return left_mul_impl<Bn254, Fq<Bn254>>(c, rows, k, lhs, col, out);
+  return WIRE_DISPATCH((left_mul_impl<Bls12_381, Fq<Bls12_381>>(c, rows, k, lhs, col, out)),
+                       (left_mul_impl<Bn254, Fq<Bn254>>(c, rows, k, lhs, col, out)));
 }
 int gs_mat_left_mul_com2(gs_ctx* c, int rows, int k, const void* lhs, const void* col, void* out) {
   RC(check_ctx(c, false));
   if (rows <= 0 || k <= 0) return GS_OK;
-  if (c->curve == 0) return left_mul_impl<Bls12_381, Fp2<Bls12_381>>(c, rows, k, lhs, col, out);
-  return left_mul_impl<Bn254, Fp2<Bn254>>(c, rows, k, lhs, col, out);
+  return WIRE_DISPATCH((left_mul_impl<Bls12_381, Fp2<Bls12_381>>(c, rows, k, lhs, col, out)),
+                       (left_mul_impl<Bn254, Fp2<Bn254>>(c, rows, k, lhs, col, out)));
 }
 
 int gs_fr_matmul(gs_ctx* c, int rows, int inner, int cols, const void* lhs, const void* rhs, void* out) {
@@ -2213,8 +2732,8 @@ int gs_fr_matmul(gs_ctx* c, int rows, int inner, int cols, const void* lhs, cons
   if (rows <= 0 || inner <= 0 || cols <= 0) return GS_OK;  // empty product
   if (!lhs || !rhs || !out) return fail(c, GS_ERR_ARG, "null pointer");
   if (rows > 4096 || inner > 4096 || cols > 4096) return fail(c, GS_ERR_SHAPE, "matrix too large");
-  if (c->curve == 0) return fr_matmul_impl<Bls12_381>(c, rows, inner, cols, lhs, rhs, out);
-  return fr_matmul_impl<Bn254>(c, rows, inner, cols, lhs, rhs, out);
+  return WIRE_DISPATCH(fr_matmul_impl<Bls12_381>(c, rows, inner, cols, lhs, rhs, out),
+                       fr_matmul_impl<Bn254>(c, rows, inner, cols, lhs, rhs, out));
 }
 
 // ---- batched (RLC) verifier ---------------------------------------------------------
@@ -2260,6 +2779,11 @@ int gs_verify_batch_rlc(gs_ctx* c, int ty, size_t N, int m, int n, const void* A
   if (ok_all) RC(gs_gt_finalize(c, 1, hacc.data(), ok_all));
   return GS_OK;
 }
+int gs_gt_finalize_dev(gs_ctx* c, size_t count, const void* accs_dev, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  if (!accs_dev || !ok || count == 0) return fail(c, GS_ERR_ARG, "null pointer");
+  return DISPATCH(c, gt_finalize(c, count, accs_dev, ok, true));
+}
 int gs_gt_finalize(gs_ctx* c, size_t count, const void* accs, uint8_t* ok) {
   RC(check_ctx(c, false));
   if (!accs || !ok || count == 0) return fail(c, GS_ERR_ARG, "null pointer");
@@ -2267,7 +2791,7 @@ int gs_gt_finalize(gs_ctx* c, size_t count, const void* accs, uint8_t* ok) {
 }
 
 // ---- profiling ---------------------------------------------------------------------
-#define WIRE_DISPATCH(expr_bls, expr_bn) (c->curve == 0 ? (expr_bls) : (expr_bn))
+
 
 int gs_wire_sizes(int curve, size_t out[6]) {
   if ((curve != 0 && curve != 1) || !out) return GS_ERR_ARG;

@@ -648,6 +648,105 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, 
   }
 }
 
+// ---- pair-cooperative twin (multi_miller_pair): two lanes per (equation, task), one accumulator each ----------------
+// Exchange policies: how a lane hands its tangent / chord line (6 L dwords) to its partner lane ^ 1.
+//  * PairLds: a 16-byte-interleaved LDS slot per lane, [6 L / 4][64] x int4 (conflict-free ds_write_b128 / ds_read_b128,
+//    21 + 21 instructions for BLS12-381); the block is ONE wave, so program order is LDS order and the barriers below
+//    are compiler fences;
+//  * PairDpp: one v_mov_b32 with quad_perm [1,0,3,2] per dword, no memory at all.
+template <class C> GS_HD int32_t& line_word(Line<C>& l, int i) {
+  constexpr int L = C::L;
+  const int c = i / L, j = i % L;
+  return c == 0 ? l.l0.c0.v[j] : c == 1 ? l.l0.c1.v[j] : c == 2 ? l.lx.c0.v[j] : c == 3 ? l.lx.c1.v[j]
+         : c == 4 ? l.ly.c0.v[j] : l.ly.c1.v[j];
+}
+template <class C> struct PairLds {
+  int4* slots;  // [6 L / 4][64]
+  int lane;
+  __device__ __forceinline__ Line<C> swap(const Line<C>& mine) const {
+    constexpr int W = 6 * C::L / 4;
+    static_assert(6 * C::L % 4 == 0, "a line is a whole number of 16-byte words");
+    Line<C> m = mine, r;
+#pragma unroll
+    for (int q = 0; q < W; q++)
+      slots[q * 64 + lane] = make_int4(line_word(m, 4 * q), line_word(m, 4 * q + 1), line_word(m, 4 * q + 2),
+                                       line_word(m, 4 * q + 3));
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+      int4 v = slots[q * 64 + (lane ^ 1)];
+      line_word(r, 4 * q) = v.x;
+      line_word(r, 4 * q + 1) = v.y;
+      line_word(r, 4 * q + 2) = v.z;
+      line_word(r, 4 * q + 3) = v.w;
+    }
+    __syncthreads();
+    return r;
+  }
+};
+template <class C> struct PairDpp {
+  __device__ __forceinline__ Line<C> swap(const Line<C>& mine) const {
+    Line<C> m = mine, r;
+#pragma unroll
+    for (int i = 0; i < 6 * C::L; i++)
+      line_word(r, i) = __builtin_amdgcn_mov_dpp(line_word(m, i), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    return r;
+  }
+};
+// Lanes are pair-major inside task-major: lane g works on component g & 1 of pair g >> 1 = (task, equation); a wave is
+// 32 equations of one task.  Same task tables and the same output layout as the twin kernel (out[2 go + a]); the
+// stepping triples of a task come first in its list (chunk_tasks), the table-reading ones after them.
+template <class C, bool DPP>
+__global__ void __launch_bounds__(64, GS_WPE) k_miller_pair(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
+                                                    ArrTab qarr, Fp12<C>* out, const Line<C>* ltab) {
+  __shared__ int4 xslots[DPP ? 1 : (6 * C::L / 4) * 64];
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;  // total is even: a pair leaves together
+  const int a = (int)(g & 1);
+  const size_t gp = g >> 1, N = total / (2 * (size_t)ntask);
+  const size_t ti = gp / N, e = gp % N;
+  const size_t go = e * ntask + ti;
+  MillerTask t = tasks[ti];
+  constexpr int OWN = (MILLER_CH + 1) / 2;
+  Aff<Fq<C>> ps[MILLER_CH];
+  Aff<Fp2<C>> qown[OWN];
+  Proj2<C> ts[OWN];
+  const Line<C>* fx[MILLER_CH];
+  int nstep = 0;
+  for (int k = 0; k < t.np; k++) {
+    fx[k] = (ltab && t.pr[k].q_arr == 2) ? ltab + (size_t)t.pr[k].q_idx * miller_line_count<C>() : nullptr;
+    if (!fx[k]) nstep = k + 1;  // (a prefix by construction)
+  }
+  uint32_t qok = 0;
+  for (int k = 0; k < t.np; k++) {
+    PairRef r = t.pr[k];
+    aff_load<C>(ps[k], parr.base[r.p_arr] + e * parr.stride[r.p_arr] + ((size_t)r.p_idx + a) * AFFB(C, Fq<C>));
+    if (r.neg) ps[k].y = neg(ps[k].y);
+    // identity test of Q on the boundary words ((0, 0) is the flag, and the Montgomery form of 0 is 0)
+    const uint32_t* qw = reinterpret_cast<const uint32_t*>(qarr.base[r.q_arr] + e * qarr.stride[r.q_arr] +
+                                                           (size_t)r.q_idx * AFFB(C, Fp2<C>));
+    uint32_t any = 0;
+    for (int w = 0; w < (int)(AFFB(C, Fp2<C>) / 4); w++) any |= qw[w];
+    if (any) qok |= 1u << k;
+  }
+  const int rounds = (nstep + 1) / 2;
+  for (int r = 0; r < rounds; r++) {
+    int k = 2 * r + a;
+    if (k >= nstep) k = nstep - 1;  // odd count: lane 1 steps a copy of the last point, never consumed
+    PairRef pr = t.pr[k];
+    aff_load<C>(qown[r], qarr.base[pr.q_arr] + e * qarr.stride[pr.q_arr] + (size_t)pr.q_idx * AFFB(C, Fp2<C>));
+  }
+  Fp12<C> f;
+  if constexpr (DPP) {
+    PairDpp<C> x;
+    multi_miller_pair(f, a, ps, qown, qok, nstep, (int)t.np, ts, fx, x);
+  } else {
+    PairLds<C> x{xslots, (int)threadIdx.x};
+    multi_miller_pair(f, a, ps, qown, qok, nstep, (int)t.np, ts, fx, x);
+  }
+  out[2 * go + a] = f;
+}
+
 // Cell c = 2a + b: product of its Miller partials (CellMap), final exponentiation,
 // compare with 1 or the PPE target (verifier.rs:50-53) -> cellok[e*4+c].
 template <class C> GS_HD_NOINLINE void cell_product(Fp12<C>& f, const Fp12<C>* mpart, size_t e, int ntask, int c,

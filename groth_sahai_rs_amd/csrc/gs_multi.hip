@@ -2,13 +2,21 @@
 // gs_ctx_create(curve, devices[], ndev) contract and 8e's partitioning.
 //
 // Equations are independent given the shared CRS, so a batch is cut into contiguous blocks of equation indices, one per
-// device; every device owns a full gs_ctx (stream, scratch, its own copy of the CRS tables) and runs the ordinary
-// single-device entry points on its block from its own host thread.  Prove and exact verify need NO collective: inputs
-// and outputs of a block never leave its device.  The batched (RLC) verifier produces one 1152-byte accumulator pair
-// per device; the cross-device reduction is a PRODUCT in Fp12, which is not an RCCL reduction operator, so the pairs
-// are all-gathered over RCCL (xGMI between the GPUs of a node; < 10 KB, latency-bound) and multiplied in device order,
-// followed by ONE final exponentiation.  RCCL is bound at run time (dlopen; the copy already in the process -- e.g.
-// PyTorch's -- is preferred so that one HIP runtime serves both) and only needed for that exchange.
+// shard; every shard owns a full gs_ctx (stream, scratch; the CRS tables are shared by the shards of one device) and
+// runs the ordinary single-device entry points on its block from its own PERSISTENT host thread (one worker per shard,
+// bound to its device once; a call posts one job per worker).  Prove and exact verify need NO collective: inputs and
+// outputs of a block never leave its device.  The batched (RLC) verifier produces one 1152-byte accumulator pair per
+// shard, written straight into the shard's exchange buffer on its device; the cross-device reduction is a PRODUCT in
+// Fp12, which is not an RCCL reduction operator, so the pairs are all-gathered (RCCL over xGMI between distinct GPUs;
+// < 10 KB, latency-bound) and multiplied in shard order on device 0, followed by ONE final exponentiation.  RCCL is
+// bound at run time (dlopen; the copy already in the process -- e.g. PyTorch's -- is preferred so that one HIP
+// runtime serves both) and only used when the shards sit on distinct devices; one shard, shards that share a device
+// (GS_MULTI_SHARED_DEVICES: how the split is tested on a one-GPU box) or a missing librccl exchange the pairs with
+// device-to-device / peer copies instead -- the same bytes in the same order.
+//
+// Two families of entry points over the same split: host pointers (whole batch in, whole batch out; every shard stages
+// its block through its context's pinned pipeline) and `_dev` (per-shard DEVICE pointer arrays: shard i's block already
+// sits on devices[i], nothing crosses PCIe; asynchronous, gs_multi_sync joins).
 #include "../../include/gs_amd.h"
 
 #include <dlfcn.h>
@@ -16,13 +24,16 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 namespace {
 
-// ---- the five RCCL entry points used, bound with dlsym -------------------------------------------------
+// ---- the RCCL entry points used, bound with dlsym -------------------------------------------------------
 typedef struct ncclComm* ncclComm_t;
 typedef int ncclResult_t;  // ncclSuccess == 0
 enum { kNcclUint8 = 1 };   // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1 (rccl.h)
@@ -73,27 +84,85 @@ static bool shape_of(int curve, int ty, Shape* s) {
   return true;
 }
 
+// one persistent host thread per shard: bound to the shard's device once, then runs the jobs posted to it
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has = false, done = false, stop = false;
+  int rc = GS_OK;
+  void start(int device) {
+    th = std::thread([this, device] {
+      hipSetDevice(device);
+      for (;;) {
+        std::function<int()> j;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [this] { return has || stop; });
+          if (stop) return;
+          j = job;
+          has = false;
+        }
+        int r = j();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          rc = r;
+          done = true;
+        }
+        cv.notify_all();
+      }
+    });
+  }
+  void post(std::function<int()> j) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(j);
+      has = true;
+      done = false;
+    }
+    cv.notify_all();
+  }
+  int wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return done; });
+    return rc;
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 }  // namespace
 
 struct gs_multi {
   int curve = 0;
   std::vector<int> devices;
   std::vector<gs_ctx*> ctx;
+  std::vector<Worker*> workers;  // empty for one shard (runs inline)
   std::string err;
-  // RCCL (bound lazily; only the batched verifier's accumulator exchange needs it)
+  bool distinct = true;  // every shard on its own device
+  // accumulator exchange (batched verifier): per shard one pair out, all pairs in; RCCL where it applies
   Rccl rccl;
   std::vector<ncclComm_t> comms;
   std::vector<hipStream_t> cstream;
-  std::vector<void*> sendb, recvb;  // per device: one pair in, ndev pairs out
-  bool rccl_tried = false, rccl_ready = false;
+  std::vector<void*> sendb, recvb;
+  bool bufs_ready = false, rccl_ready = false, rccl_failed = false;
+  std::string rccl_why;
   size_t gt = 0;
+  std::vector<uint8_t> one;  // the GT identity in boundary form (accumulator pair of an empty block)
 };
 
 static int mfail(gs_multi* m, int code, const std::string& what) {
   if (m) m->err = what;
   return code;
 }
-// contiguous block [lo, hi) of equation indices of device i (sizes differ by at most one)
+// contiguous block [lo, hi) of equation indices of shard i (sizes differ by at most one)
 static void block(size_t N, int ndev, int i, size_t* lo, size_t* hi) {
   size_t base = N / ndev, rem = N % ndev;
   *lo = i * base + ((size_t)i < rem ? (size_t)i : rem);
@@ -102,59 +171,133 @@ static void block(size_t N, int ndev, int i, size_t* lo, size_t* hi) {
 static inline const uint8_t* off(const void* p, size_t bytes) { return p ? (const uint8_t*)p + bytes : nullptr; }
 static inline uint8_t* offw(void* p, size_t bytes) { return p ? (uint8_t*)p + bytes : nullptr; }
 
-// run fn(i) for every device on its own host thread; first non-zero status wins
+// run fn(i) for every shard on its worker; first non-zero status wins
 template <class F> static int on_all(gs_multi* m, F fn) {
   int nd = (int)m->ctx.size();
   std::vector<int> rc(nd, GS_OK);
-  if (nd == 1) {
-    rc[0] = fn(0);
+  if (m->workers.empty()) {
+    for (int i = 0; i < nd; i++) rc[i] = fn(i);
   } else {
-    std::vector<std::thread> th;
-    for (int i = 0; i < nd; i++) th.emplace_back([&, i] { rc[i] = fn(i); });
-    for (auto& t : th) t.join();
+    for (int i = 0; i < nd; i++) m->workers[i]->post([&fn, i] { return fn(i); });
+    for (int i = 0; i < nd; i++) rc[i] = m->workers[i]->wait();
   }
   for (int i = 0; i < nd; i++)
     if (rc[i] != GS_OK) {
       char b[64];
-      snprintf(b, sizeof b, "device %d: ", m->devices[i]);
+      snprintf(b, sizeof b, "shard %d (device %d): ", i, m->devices[i]);
       m->err = std::string(b) + gs_last_error(m->ctx[i]);
       return rc[i];
     }
   return GS_OK;
 }
 
-static int rccl_setup(gs_multi* m) {
-  if (m->rccl_tried) return m->rccl_ready ? GS_OK : GS_ERR_DEVICE;
-  m->rccl_tried = true;
-  m->rccl = load_rccl();
-  if (!m->rccl.ok()) return mfail(m, GS_ERR_DEVICE, "RCCL (librccl.so) could not be loaded");
+// exchange buffers (always) and, for distinct devices, the RCCL communicators.  A failure to bring RCCL up is
+// remembered with its reason and the exchange falls back to peer copies; a failed buffer allocation is retried by the
+// next call (nothing sticky but what succeeded).
+static int exchange_setup(gs_multi* m) {
   int nd = (int)m->ctx.size();
-  m->comms.assign(nd, nullptr);
-  ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), nd, m->devices.data());
-  if (r != 0)
-    return mfail(m, GS_ERR_DEVICE, std::string("ncclCommInitAll: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(r) : "?"));
-  m->cstream.assign(nd, nullptr);
-  m->sendb.assign(nd, nullptr);
-  m->recvb.assign(nd, nullptr);
-  for (int i = 0; i < nd; i++) {
-    if (hipSetDevice(m->devices[i]) != hipSuccess || hipStreamCreateWithFlags(&m->cstream[i], hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&m->sendb[i], 2 * m->gt) != hipSuccess || hipMalloc(&m->recvb[i], (size_t)nd * 2 * m->gt) != hipSuccess)
-      return mfail(m, GS_ERR_ALLOC, "RCCL exchange buffers");
+  if (!m->bufs_ready) {
+    m->cstream.resize(nd, nullptr);
+    m->sendb.resize(nd, nullptr);
+    m->recvb.resize(nd, nullptr);
+    for (int i = 0; i < nd; i++) {
+      if (hipSetDevice(m->devices[i]) != hipSuccess) return mfail(m, GS_ERR_DEVICE, "hipSetDevice");
+      if (!m->cstream[i] && hipStreamCreateWithFlags(&m->cstream[i], hipStreamNonBlocking) != hipSuccess)
+        return mfail(m, GS_ERR_DEVICE, "exchange stream");
+      if (!m->sendb[i] && hipMalloc(&m->sendb[i], 2 * m->gt) != hipSuccess) return mfail(m, GS_ERR_ALLOC, "exchange buffers");
+      if (!m->recvb[i] && hipMalloc(&m->recvb[i], (size_t)nd * 2 * m->gt) != hipSuccess)
+        return mfail(m, GS_ERR_ALLOC, "exchange buffers");
+    }
+    m->bufs_ready = true;
   }
-  m->rccl_ready = true;
+  if (nd > 1 && m->distinct && !m->rccl_ready && !m->rccl_failed) {
+    m->rccl = load_rccl();
+    if (!m->rccl.ok()) {
+      m->rccl_failed = true;
+      m->rccl_why = "librccl.so could not be loaded";
+    } else {
+      m->comms.assign(nd, nullptr);
+      ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), nd, m->devices.data());
+      if (r != 0) {
+        m->rccl_failed = true;
+        m->rccl_why = std::string("ncclCommInitAll: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(r) : "?");
+        m->comms.clear();
+      } else {
+        m->rccl_ready = true;
+      }
+    }
+  }
+  return GS_OK;
+}
+
+// every shard's pair sits in sendb[i] (its context's stream has been drained): all nd pairs, in shard order, into
+// every recvb[i]
+static int exchange_pairs(gs_multi* m) {
+  int nd = (int)m->ctx.size();
+  const size_t pair = 2 * m->gt;
+  if (m->rccl_ready) {
+    m->rccl.GroupStart();
+    for (int i = 0; i < nd; i++) {
+      ncclResult_t r = m->rccl.AllGather(m->sendb[i], m->recvb[i], pair, kNcclUint8, m->comms[i], m->cstream[i]);
+      if (r != 0) {
+        m->rccl.GroupEnd();
+        return mfail(m, GS_ERR_DEVICE, std::string("ncclAllGather: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(r) : "?"));
+      }
+    }
+    if (m->rccl.GroupEnd() != 0) return mfail(m, GS_ERR_DEVICE, "ncclGroupEnd");
+  } else {
+    for (int i = 0; i < nd; i++) {
+      if (hipSetDevice(m->devices[i]) != hipSuccess) return mfail(m, GS_ERR_DEVICE, "hipSetDevice");
+      for (int j = 0; j < nd; j++) {
+        uint8_t* dst = (uint8_t*)m->recvb[i] + (size_t)j * pair;
+        hipError_t e = m->devices[i] == m->devices[j]
+                           ? hipMemcpyAsync(dst, m->sendb[j], pair, hipMemcpyDeviceToDevice, m->cstream[i])
+                           : hipMemcpyPeerAsync(dst, m->devices[i], m->sendb[j], m->devices[j], pair, m->cstream[i]);
+        if (e != hipSuccess) return mfail(m, GS_ERR_DEVICE, std::string("pair exchange: ") + hipGetErrorString(e));
+      }
+    }
+  }
+  for (int i = 0; i < nd; i++)
+    if (hipSetDevice(m->devices[i]) != hipSuccess || hipStreamSynchronize(m->cstream[i]) != hipSuccess)
+      return mfail(m, GS_ERR_DEVICE, "pair exchange (sync)");
+  return GS_OK;
+}
+
+// after the shards wrote their pairs: gather, cross-check, one final exponentiation on device 0
+static int finish_rlc(gs_multi* m, void* acc_pairs, uint8_t* ok_all) {
+  int nd = (int)m->ctx.size();
+  const size_t pair = 2 * m->gt;
+  int rc = exchange_pairs(m);
+  if (rc != GS_OK) return rc;
+  // every shard must have received the same bytes (a wrong rank order or a torn transfer would change the verdict)
+  std::vector<uint8_t> gathered((size_t)nd * pair), check((size_t)nd * pair);
+  for (int i = 0; i < nd; i++) {
+    if (hipSetDevice(m->devices[i]) != hipSuccess ||
+        hipMemcpy(i == 0 ? gathered.data() : check.data(), m->recvb[i], (size_t)nd * pair, hipMemcpyDeviceToHost) != hipSuccess)
+      return mfail(m, GS_ERR_DEVICE, "accumulator download");
+    if (i > 0 && memcmp(check.data(), gathered.data(), gathered.size()) != 0)
+      return mfail(m, GS_ERR_DEVICE, "gathered accumulator pairs differ between shards");
+  }
+  if (acc_pairs) memcpy(acc_pairs, gathered.data(), gathered.size());
+  // product in shard order + ONE final exponentiation, on device 0, from its own receive buffer
+  rc = gs_gt_finalize_dev(m->ctx[0], (size_t)nd, m->recvb[0], ok_all);
+  if (rc != GS_OK) return mfail(m, rc, gs_last_error(m->ctx[0]));
   return GS_OK;
 }
 
 extern "C" {
 
-int gs_ctx_create_multi(int curve, const int* devices, int ndev, gs_multi** out) {
+int gs_ctx_create_multi_ex(int curve, const int* devices, int ndev, int flags, gs_multi** out) {
   if (!out || !devices || ndev < 1 || ndev > 64 || (curve != 0 && curve != 1)) return GS_ERR_ARG;
   *out = nullptr;
+  bool distinct = true;
   for (int i = 0; i < ndev; i++)
     for (int k = 0; k < i; k++)
-      if (devices[i] == devices[k]) return GS_ERR_ARG;  // one context per device
+      if (devices[i] == devices[k]) distinct = false;
+  if (!distinct && !(flags & GS_MULTI_SHARED_DEVICES)) return GS_ERR_ARG;  // one context per device unless asked for
   gs_multi* m = new gs_multi();
   m->curve = curve;
+  m->distinct = distinct;
   size_t sz[6];
   gs_sizes(curve, sz);
   m->gt = sz[4];
@@ -162,19 +305,30 @@ int gs_ctx_create_multi(int curve, const int* devices, int ndev, gs_multi** out)
     gs_ctx* c = nullptr;
     int rc = gs_ctx_create(curve, devices[i], &c);
     if (rc != GS_OK) {
-      for (gs_ctx* p : m->ctx) gs_ctx_destroy(p);
-      delete m;
+      gs_multi_destroy(m);
       return rc;
     }
     m->devices.push_back(devices[i]);
     m->ctx.push_back(c);
   }
+  if (ndev > 1)
+    for (int i = 0; i < ndev; i++) {
+      m->workers.push_back(new Worker());
+      m->workers.back()->start(devices[i]);
+    }
   *out = m;
   return GS_OK;
+}
+int gs_ctx_create_multi(int curve, const int* devices, int ndev, gs_multi** out) {
+  return gs_ctx_create_multi_ex(curve, devices, ndev, 0, out);
 }
 
 void gs_multi_destroy(gs_multi* m) {
   if (!m) return;
+  for (Worker* w : m->workers) {
+    w->shutdown();
+    delete w;
+  }
   for (size_t i = 0; i < m->ctx.size(); i++) {
     hipSetDevice(m->devices[i]);
     if (i < m->cstream.size() && m->cstream[i]) {
@@ -193,6 +347,14 @@ int gs_multi_ndev(gs_multi* m) { return m ? (int)m->ctx.size() : 0; }
 gs_ctx* gs_multi_ctx(gs_multi* m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[i] : nullptr; }
 const char* gs_multi_last_error(gs_multi* m) { return m ? m->err.c_str() : "null context"; }
 int gs_multi_uses_rccl(gs_multi* m) { return (m && m->rccl_ready) ? 1 : 0; }
+const char* gs_multi_exchange_note(gs_multi* m) {
+  if (!m) return "null context";
+  if (m->rccl_ready) return "rccl all-gather";
+  if (m->ctx.size() == 1) return "one shard: device-to-device copy";
+  if (!m->distinct) return "shards share a device: device-to-device copies";
+  if (m->rccl_failed) return m->rccl_why.c_str();
+  return "not set up yet";
+}
 
 int gs_multi_shard(gs_multi* m, size_t N, int i, size_t* lo, size_t* hi) {
   if (!m || !lo || !hi || i < 0 || (size_t)i >= m->ctx.size()) return GS_ERR_ARG;
@@ -202,9 +364,23 @@ int gs_multi_shard(gs_multi* m, size_t N, int i, size_t* lo, size_t* hi) {
 
 int gs_multi_set_crs(gs_multi* m, const void* crs) {
   if (!m || !crs) return GS_ERR_ARG;
+  // (shards of one device: the first builds the tables, the others find and share them)
+  if (!m->distinct) {
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+      int rc = gs_set_crs(m->ctx[i], crs);
+      if (rc != GS_OK) return mfail(m, rc, gs_last_error(m->ctx[i]));
+    }
+    return GS_OK;
+  }
   return on_all(m, [&](int i) { return gs_set_crs(m->ctx[i], crs); });
 }
 
+int gs_multi_sync(gs_multi* m) {
+  if (!m) return GS_ERR_ARG;
+  return on_all(m, [&](int i) { return gs_sync(m->ctx[i]); });
+}
+
+// ---- host pointers: whole batch in, whole batch out ------------------------------------------------------------
 int gs_multi_prove_batch(gs_multi* m, int ty, size_t N, int mm, int n, const void* X, const void* Y, const void* A,
                          const void* B, const void* G, const void* R, const void* S, const void* T, void* xcoms,
                          void* ycoms, void* pi, void* theta) {
@@ -246,74 +422,113 @@ int gs_multi_verify_batch(gs_multi* m, int ty, size_t N, int mm, int n, const vo
   });
 }
 
+static int rlc_prologue(gs_multi* m, int ty, size_t N, int mm, int n, Shape* s) {
+  if (!shape_of(m->curve, ty, s)) return mfail(m, GS_ERR_ARG, "bad equation type");
+  if (mm < 1 || n < 1) return mfail(m, GS_ERR_SHAPE, "m and n must be >= 1");
+  if (N == 0) return mfail(m, GS_ERR_ARG, "empty batch");
+  int rc = exchange_setup(m);
+  if (rc != GS_OK) return rc;
+  if (m->one.empty()) {  // the accumulator pair of an empty block is (1, 1): E::multi_pairing of no pairs
+    m->one.resize(m->gt);
+    rc = gs_multi_pairing_batch(m->ctx[0], 1, 0, m->one.data(), m->one.data(), m->one.data());
+    if (rc != GS_OK) {
+      m->one.clear();
+      return mfail(m, rc, gs_last_error(m->ctx[0]));
+    }
+  }
+  return GS_OK;
+}
+static int empty_pair(gs_multi* m, int i) {
+  if (hipMemcpy(m->sendb[i], m->one.data(), m->gt, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy((uint8_t*)m->sendb[i] + m->gt, m->one.data(), m->gt, hipMemcpyHostToDevice) != hipSuccess)
+    return GS_ERR_DEVICE;
+  return GS_OK;
+}
+
 int gs_multi_verify_batch_rlc(gs_multi* m, int ty, size_t N, int mm, int n, const void* A, const void* B, const void* G,
                               const void* target, const void* xcoms, const void* ycoms, const void* pi,
                               const void* theta, const uint64_t* rho, void* acc_pairs, uint8_t* ok_all) {
   if (!m || !ok_all) return GS_ERR_ARG;
+  if (!rho) return mfail(m, GS_ERR_ARG, "rho is NULL (see the rho contract in gs_amd.h)");
   Shape s;
-  if (!shape_of(m->curve, ty, &s)) return mfail(m, GS_ERR_ARG, "bad equation type");
-  if (mm < 1 || n < 1) return mfail(m, GS_ERR_SHAPE, "m and n must be >= 1");
-  if (N == 0) return mfail(m, GS_ERR_ARG, "empty batch");
+  int rc = rlc_prologue(m, ty, N, mm, n, &s);
+  if (rc != GS_OK) return rc;
   int nd = (int)m->ctx.size();
   const size_t pair = 2 * m->gt;
-  // the accumulator pair of an empty block is (1, 1): E::multi_pairing of no pairs
-  std::vector<uint8_t> one(m->gt);
-  {
-    int rc = gs_multi_pairing_batch(m->ctx[0], 1, 0, one.data(), one.data(), one.data());
-    if (rc != GS_OK) return mfail(m, rc, gs_last_error(m->ctx[0]));
-  }
-  std::vector<uint8_t> local((size_t)nd * pair);
-  int rc = on_all(m, [&](int i) {
+  rc = on_all(m, [&](int i) {
     size_t lo, hi;
     block(N, nd, i, &lo, &hi);
-    uint8_t* acc = &local[(size_t)i * pair];
-    if (hi == lo) {
-      memcpy(acc, one.data(), m->gt);
-      memcpy(acc + m->gt, one.data(), m->gt);
-      return (int)GS_OK;
-    }
+    if (hi == lo) return empty_pair(m, i);
     size_t um = (size_t)mm, un = (size_t)n;
-    return gs_verify_batch_rlc(m->ctx[i], ty, hi - lo, mm, n, off(A, lo * un * s.sx), off(B, lo * um * s.sy),
-                               off(G, lo * um * un * s.fr), off(target, lo * s.st), off(xcoms, lo * um * 4 * s.fq),
-                               off(ycoms, lo * un * 8 * s.fq), off(pi, lo * s.kx * 8 * s.fq),
-                               off(theta, lo * s.ky * 4 * s.fq), rho + 4 * lo, acc, nullptr);
+    // (host inputs: the shard's pair comes back with them and goes up into its exchange buffer, 1152 bytes)
+    std::vector<uint8_t> acc(pair);
+    int r = gs_verify_batch_rlc(m->ctx[i], ty, hi - lo, mm, n, off(A, lo * un * s.sx), off(B, lo * um * s.sy),
+                                off(G, lo * um * un * s.fr), off(target, lo * s.st), off(xcoms, lo * um * 4 * s.fq),
+                                off(ycoms, lo * un * 8 * s.fq), off(pi, lo * s.kx * 8 * s.fq),
+                                off(theta, lo * s.ky * 4 * s.fq), rho + 4 * lo, acc.data(), nullptr);
+    if (r != GS_OK) return r;
+    return hipMemcpy(m->sendb[i], acc.data(), pair, hipMemcpyHostToDevice) == hipSuccess ? (int)GS_OK : (int)GS_ERR_DEVICE;
   });
   if (rc != GS_OK) return rc;
-  // all-gather of the pairs over RCCL: every device ends with all nd pairs in device order
-  std::vector<uint8_t> gathered((size_t)nd * pair);
-  rc = rccl_setup(m);
-  if (rc != GS_OK) return rc;
-  for (int i = 0; i < nd; i++) {
-    if (hipSetDevice(m->devices[i]) != hipSuccess ||
-        hipMemcpyAsync(m->sendb[i], &local[(size_t)i * pair], pair, hipMemcpyHostToDevice, m->cstream[i]) != hipSuccess)
-      return mfail(m, GS_ERR_DEVICE, "accumulator upload");
-  }
-  m->rccl.GroupStart();
-  for (int i = 0; i < nd; i++) {
-    ncclResult_t r = m->rccl.AllGather(m->sendb[i], m->recvb[i], pair, kNcclUint8, m->comms[i], m->cstream[i]);
-    if (r != 0) {
-      m->rccl.GroupEnd();
-      return mfail(m, GS_ERR_DEVICE, std::string("ncclAllGather: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(r) : "?"));
-    }
-  }
-  if (m->rccl.GroupEnd() != 0) return mfail(m, GS_ERR_DEVICE, "ncclGroupEnd");
-  std::vector<uint8_t> check((size_t)nd * pair);
-  for (int i = 0; i < nd; i++) {
-    if (hipSetDevice(m->devices[i]) != hipSuccess ||
-        hipMemcpyAsync(i == 0 ? gathered.data() : check.data(), m->recvb[i], (size_t)nd * pair, hipMemcpyDeviceToHost,
-                       m->cstream[i]) != hipSuccess ||
-        hipStreamSynchronize(m->cstream[i]) != hipSuccess)
-      return mfail(m, GS_ERR_DEVICE, "accumulator download");
-    if (i > 0 && memcmp(check.data(), gathered.data(), gathered.size()) != 0)
-      return mfail(m, GS_ERR_DEVICE, "all-gather results differ between devices");
-  }
-  if (memcmp(gathered.data(), local.data(), local.size()) != 0)
-    return mfail(m, GS_ERR_DEVICE, "all-gather did not return the pairs in device order");
-  if (acc_pairs) memcpy(acc_pairs, gathered.data(), gathered.size());
-  // product in device order + ONE final exponentiation (device 0)
-  rc = gs_gt_finalize(m->ctx[0], (size_t)nd, gathered.data(), ok_all);
-  if (rc != GS_OK) return mfail(m, rc, gs_last_error(m->ctx[0]));
-  return GS_OK;
+  return finish_rlc(m, acc_pairs, ok_all);
 }
+
+// ---- device-resident shards: per-shard pointer arrays, nothing crosses PCIe --------------------------------------
+#define PP(a) ((a) ? (a)[i] : nullptr)
+int gs_multi_prove_batch_dev(gs_multi* m, int ty, size_t N, int mm, int n, const void* const* X, const void* const* Y,
+                             const void* const* A, const void* const* B, const void* const* G, const void* const* R,
+                             const void* const* S, const void* const* T, void* const* xcoms, void* const* ycoms,
+                             void* const* pi, void* const* theta) {
+  if (!m) return GS_ERR_ARG;
+  if (!X || !Y || !A || !B || !G || !R || !S || !T || !pi || !theta) return mfail(m, GS_ERR_ARG, "null pointer array");
+  int nd = (int)m->ctx.size();
+  return on_all(m, [&](int i) {
+    size_t lo, hi;
+    block(N, nd, i, &lo, &hi);
+    if (hi == lo) return (int)GS_OK;
+    return gs_prove_batch_dev(m->ctx[i], ty, hi - lo, mm, n, X[i], Y[i], A[i], B[i], G[i], R[i], S[i], T[i], PP(xcoms),
+                              PP(ycoms), pi[i], theta[i]);
+  });
+}
+int gs_multi_verify_batch_dev(gs_multi* m, int ty, size_t N, int mm, int n, const void* const* A, const void* const* B,
+                              const void* const* G, const void* const* target, const void* const* xcoms,
+                              const void* const* ycoms, const void* const* pi, const void* const* theta,
+                              uint8_t* const* ok) {
+  if (!m) return GS_ERR_ARG;
+  if (!A || !B || !G || !target || !xcoms || !ycoms || !pi || !theta || !ok) return mfail(m, GS_ERR_ARG, "null pointer array");
+  int nd = (int)m->ctx.size();
+  return on_all(m, [&](int i) {
+    size_t lo, hi;
+    block(N, nd, i, &lo, &hi);
+    if (hi == lo) return (int)GS_OK;
+    return gs_verify_batch_dev(m->ctx[i], ty, hi - lo, mm, n, A[i], B[i], G[i], target[i], xcoms[i], ycoms[i], pi[i],
+                               theta[i], ok[i]);
+  });
+}
+// rho[i]: shard i's exponents on ITS device, 4 per equation of its block (the caller cuts the global rho array with
+// gs_multi_shard).  The shard's pair is written by the engine straight into its exchange buffer.
+int gs_multi_verify_batch_rlc_dev(gs_multi* m, int ty, size_t N, int mm, int n, const void* const* A,
+                                  const void* const* B, const void* const* G, const void* const* target,
+                                  const void* const* xcoms, const void* const* ycoms, const void* const* pi,
+                                  const void* const* theta, const uint64_t* const* rho, void* acc_pairs,
+                                  uint8_t* ok_all) {
+  if (!m || !ok_all) return GS_ERR_ARG;
+  if (!A || !B || !G || !target || !xcoms || !ycoms || !pi || !theta || !rho) return mfail(m, GS_ERR_ARG, "null pointer array");
+  Shape s;
+  int rc = rlc_prologue(m, ty, N, mm, n, &s);
+  if (rc != GS_OK) return rc;
+  int nd = (int)m->ctx.size();
+  rc = on_all(m, [&](int i) {
+    size_t lo, hi;
+    block(N, nd, i, &lo, &hi);
+    if (hi == lo) return empty_pair(m, i);
+    int r = gs_verify_batch_rlc_dev(m->ctx[i], ty, hi - lo, mm, n, A[i], B[i], G[i], target[i], xcoms[i], ycoms[i], pi[i],
+                                    theta[i], rho[i], m->sendb[i]);
+    return r != GS_OK ? r : gs_sync(m->ctx[i]);
+  });
+  if (rc != GS_OK) return rc;
+  return finish_rlc(m, acc_pairs, ok_all);
+}
+#undef PP
 
 }  // extern "C"

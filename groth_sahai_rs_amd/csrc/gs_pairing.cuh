@@ -341,6 +341,93 @@ GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0out, Fp12<C>& f1out, const Aff<Fq<C
   }
 }
 
+// Pair-cooperative twin Miller loop: the twin loop above spread over TWO lanes.  Lanes 2i and 2i + 1 of a wave work on
+// the same (equation, task): lane a owns the accumulator of component a for the whole loop (ONE accumulator per lane:
+// it fits the register file, the two of multi_miller2 do not and stream through memory at every line product), the
+// stepping twist points of the task are dealt out alternately (lane a steps triples a, a + 2, ...), and every tangent /
+// chord line crosses to the partner lane once through the exchange policy X (LDS slots or DPP on the device).  Total
+// work is that of the twin loop: the same squarings per accumulator, every line computed once and evaluated at both
+// G1 components (data_structures.rs:494-502).
+//   ps[k]     the lane's OWN G1 component of every triple, k < np (stepping triples first: k < nstep)
+//   qown[r]   the twist point of the lane's r-th stepping triple, k = 2 r + a, r < (nstep + 1) / 2 (with nstep odd the
+//             last lane-1 entry is any valid point: it is stepped and never consumed)
+//   qok       bit k: Q_k is not the identity (the same on both lanes)
+//   fixed[k]  line table of a CRS G2 argument (k >= nstep), consumed as in multi_miller
+// X::swap(l) returns the partner lane's line; both lanes of a pair always reach it together.
+template <class C, class X>
+GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const Aff<Fp2<C>>* qown, uint32_t qok,
+                                      int nstep, int np, Proj2<C>* ts, const Line<C>* const* fixed, X& xch) {
+  Fp12<C> f;  // local: the whole point of this shape
+  f12_one(f);
+  uint32_t live = 0;
+  for (int k = 0; k < np; k++)
+    if (((qok >> k) & 1) && !aff_is_inf(ps[k])) live |= 1u << k;
+  const int rounds = (nstep + 1) / 2;
+  for (int r = 0; r < rounds; r++) {
+    const Aff<Fp2<C>>& q = qown[r];
+    ts[r].x = q.x;
+    ts[r].y = q.y;
+    ts[r].z = one_of<Fp2<C>>();
+  }
+  Line<C> l, lp;
+  LineAcc<C> acc;
+  int li = 0;
+  for (int i = C::LOOP_LEN - 2; i >= 0; i--) {
+    acc.flush(f);
+    f12_sqr(f, f);
+    for (int r = 0; r < rounds; r++) {
+      const int ko = 2 * r + a, kp = 2 * r + 1 - a;
+      miller_dbl(ts[r], l);
+      lp = xch.swap(l);
+      if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
+      if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
+    }
+    for (int k = nstep; k < np; k++)
+      if ((live >> k) & 1) acc.add(f, fixed[k][li], ps[k]);
+    li++;
+    int d = C::LOOP[i];
+    if (d != 0) {
+      for (int r = 0; r < rounds; r++) {
+        const int ko = 2 * r + a, kp = 2 * r + 1 - a;
+        Aff<Fp2<C>> q = qown[r];
+        if (d < 0) q.y = neg(q.y);
+        miller_add(ts[r], l, q);
+        lp = xch.swap(l);
+        if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
+        if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
+      }
+      for (int k = nstep; k < np; k++)
+        if ((live >> k) & 1) acc.add(f, fixed[k][li], ps[k]);
+      li++;
+    }
+  }
+  if (C::IS_BN) {
+    for (int e = 0; e < 2; e++) {
+      for (int r = 0; r < rounds; r++) {
+        const int ko = 2 * r + a, kp = 2 * r + 1 - a;
+        const Aff<Fp2<C>>& q = qown[r];
+        Aff<Fp2<C>> qf;
+        if (e == 0) {
+          qf.x = mul(conj(q.x), frob_coeff<C>(1, 2));
+          qf.y = mul(conj(q.y), frob_coeff<C>(1, 3));
+        } else {
+          qf.x = mul(q.x, frob_coeff<C>(2, 2));
+          qf.y = neg(mul(q.y, frob_coeff<C>(2, 3)));
+        }
+        miller_add(ts[r], l, qf);
+        lp = xch.swap(l);
+        if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
+        if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
+      }
+      for (int k = nstep; k < np; k++)
+        if ((live >> k) & 1) acc.add(f, fixed[k][li + e], ps[k]);
+    }
+  }
+  acc.flush(f);
+  if (C::LOOP_NEG) f12_conj(f, f);
+  fout = f;
+}
+
 // f^|x| by square-and-multiply over the 64-bit curve parameter, cyclotomic
 // squarings; then conjugate if x < 0 (so the result is f^x).
 template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f) {

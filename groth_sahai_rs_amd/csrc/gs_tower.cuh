@@ -28,6 +28,9 @@
 #define GS_F6 GS_HD_NOINLINE
 #endif
 // experiment: inline the Fp12 squaring / sparse product and the Miller steps into the loop
+#if (defined(GS_MILLER_INLINE) || defined(GS_FE_INLINE)) && !defined(GS_LONGBR_OK) && defined(__HIPCC__)
+#error "GS_MILLER_INLINE / GS_FE_INLINE need -mllvm -amdgpu-long-branch-factor=0 (csrc/Makefile probes it and passes -DGS_LONGBR_OK): without it the reserved long-branch register aliases the return address and the kernels never return"
+#endif
 #if defined(GS_MILLER_INLINE)
 #define GS_ML GS_HD
 #else

@@ -277,3 +277,95 @@ class Statement:
             _cat(com_proof.xcoms.coms, 0), _cat(com_proof.ycoms.coms, 0),
             cat([_cat(pf.pi, 0) for pf in com_proof.equ_proofs]), cat([_cat(pf.theta, 0) for pf in com_proof.equ_proofs]))
         return [bool(v) for v in ok]
+
+
+class MixedProof:
+    """Commitments of the four variable groups of a mixed-type Statement and one EquProof per equation."""
+
+    def __init__(self, com_xg, com_yg, com_xs, com_ys, equ_proofs):
+        self.com_xg, self.com_yg, self.com_xs, self.com_ys, self.equ_proofs = com_xg, com_yg, com_xs, com_ys, equ_proofs
+
+
+class MixedStatement:
+    """`Statement = Vec<dyn Equ>` (statement.rs:24-28,109) with equations of ANY type over one list of variables:
+    G1 variables xg, G2 variables yg and scalar variables xs (committed into B1), ys (into B2).  A PPE is over
+    (xg, yg), an MSMEG1 over (xg, ys), an MSMEG2 over (xs, yg), a QuadEqu over (xs, ys)  (statement.rs:117-192: which
+    side of each type is a group element).  Every group is committed ONCE (batch_commit_G1 / _G2 / _scalar_to_B1 /
+    _scalar_to_B2), every equation gets its own EquProof against those commitments -- what the reference does when
+    one calls `equ.prove(..)` per equation with shared Commit1 / Commit2 -- and all equations of all types go to the
+    engine in ONE call (gs_prove_mixed / gs_verify_mixed with shared_vars parts).  RNG draw order: the four commit
+    randomness matrices (xg, yg, xs, ys), then T of equation 0, 1, ..."""
+
+    def __init__(self, equations):
+        assert len(equations) >= 1
+        self.equations = list(equations)
+
+    @staticmethod
+    def _groups(ty):
+        return ("xg" if ty in (GS_PPE, GS_MSMEG1) else "xs"), ("yg" if ty in (GS_PPE, GS_MSMEG2) else "ys")
+
+    def _by_type(self):
+        order = []
+        for e in self.equations:
+            if e.TYPE not in order:
+                order.append(e.TYPE)
+        return [(ty, [i for i, e in enumerate(self.equations) if e.TYPE == ty]) for ty in order]
+
+    def commit_and_prove(self, xg, yg, xs, ys, crs, rng):
+        vars_ = dict(xg=xg, yg=yg, xs=xs, ys=ys)
+        coms = dict(xg=batch_commit_G1(xg, crs, rng), yg=batch_commit_G2(yg, crs, rng),
+                    xs=batch_commit_scalar_to_B1(xs, crs, rng), ys=batch_commit_scalar_to_B2(ys, crs, rng))
+        Ts = []
+        for e in self.equations:
+            kx, ky = e._kxky()
+            Ts.append([[rng.fr() for _ in range(kx)] for _ in range(ky)])
+        cat = np.concatenate
+        parts = []
+        for ty, idx in self._by_type():
+            gx, gy = self._groups(ty)
+            m, n = len(vars_[gx]), len(vars_[gy])
+            assert m >= 1 and n >= 1
+            eqs = [self.equations[i] for i in idx]
+            for e in eqs:
+                e._check_statement_shape(m, n)
+            parts.append(dict(ty=ty, N=len(idx), m=m, n=n, shared=True, want_coms=False, X=_cat(vars_[gx], 0),
+                              Y=_cat(vars_[gy], 0), A=cat([_cat(e.a_consts, 0) for e in eqs]),
+                              B=cat([_cat(e.b_consts, 0) for e in eqs]), Gamma=cat([_flat_mat(e.gamma) for e in eqs]),
+                              R=_flat_mat(coms[gx].rand), S=_flat_mat(coms[gy].rand),
+                              T=cat([_flat_mat(Ts[i]) for i in idx])))
+        outs = crs.engine.prove_mixed(parts)
+        proofs = [None] * len(self.equations)
+        for (ty, idx), o in zip(self._by_type(), outs):
+            kx, ky = self.equations[idx[0]]._kxky()
+            pis, ths = _split(o["pi"], len(idx) * kx), _split(o["theta"], len(idx) * ky)
+            for k, i in enumerate(idx):
+                proofs[i] = EquProof(pis[k * kx:(k + 1) * kx], ths[k * ky:(k + 1) * ky], ty, Ts[i])
+        return MixedProof(coms["xg"], coms["yg"], coms["xs"], coms["ys"], proofs)
+
+    def verify(self, proof, crs):
+        """[bool per equation], in the order of the statement's equations"""
+        coms = dict(xg=proof.com_xg, yg=proof.com_yg, xs=proof.com_xs, ys=proof.com_ys)
+        assert len(proof.equ_proofs) == len(self.equations)
+        cat = np.concatenate
+        parts = []
+        for ty, idx in self._by_type():
+            gx, gy = self._groups(ty)
+            m, n = len(coms[gx].coms), len(coms[gy].coms)
+            assert m >= 1 and n >= 1
+            eqs = [self.equations[i] for i in idx]
+            pfs = [proof.equ_proofs[i] for i in idx]
+            kx, ky = eqs[0]._kxky()
+            for e, pf in zip(eqs, pfs):
+                e._check_statement_shape(m, n)
+                assert pf.equ_type == ty and len(pf.pi) == kx and len(pf.theta) == ky
+            parts.append(dict(ty=ty, N=len(idx), m=m, n=n, shared=True, A=cat([_cat(e.a_consts, 0) for e in eqs]),
+                              B=cat([_cat(e.b_consts, 0) for e in eqs]), Gamma=cat([_flat_mat(e.gamma) for e in eqs]),
+                              target=cat([np.asarray(e.target, dtype=np.uint64).reshape(-1) for e in eqs]),
+                              xcoms=_cat(coms[gx].coms, 0), ycoms=_cat(coms[gy].coms, 0),
+                              pi=cat([_cat(pf.pi, 0) for pf in pfs]), theta=cat([_cat(pf.theta, 0) for pf in pfs])))
+        oks = crs.engine.verify_mixed(parts)
+        out = [None] * len(self.equations)
+        for (ty, idx), ok in zip(self._by_type(), oks):
+            for k, i in enumerate(idx):
+                out[i] = bool(ok[k])
+        return out

@@ -71,6 +71,8 @@ void gs_ctx_destroy(gs_ctx* ctx);
 int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default stream */
 /* Planner overrides (results never change, only which kernel shapes run; tests force every shape through them):
  *   "miller_twin"  -1 planned | 0 one accumulator per Miller lane | 1 two (lines of Q shared by both G1 partners)
+ *                   | 2 the same triples on a PAIR of lanes, one accumulator each, lines exchanged through LDS | 3 the
+ *                   same with a DPP exchange
  *   "miller_ch"     0 planned | 1..12 pairs (triples) per Miller lane
  *   "var_tm"        0 planned | 1..8 variable-base terms per Straus lane
  *   "var_mo"        0 planned | 1, 2, 4 outputs over the same bases served by one lane's table build
@@ -83,7 +85,8 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream
  * The same knobs are read ONCE at gs_ctx_create from the environment for experiments without recompiling the caller:
  * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_VAR_MO, GS_VAR_W, GS_RED_K, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP (same values).
- * Unset = planned. */
+ * Unset = planned.  GS_COPY_THREADS (default 4): memcpy workers of the host-pointer entry points; GS_ROCTX=1: load the
+ * roctx library for phase markers ("gs.prove", "gs.prove.g1", "gs.verify.miller" ...) even when no profiler mapped it. */
 int gs_set_option(gs_ctx* ctx, const char* key, int value);
 int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the context's stream */
 const char* gs_last_error(gs_ctx* ctx);
@@ -122,7 +125,13 @@ int gs_commit_fr_b2(gs_ctx*, size_t count, const void* y_fr, const void* rand_fr
 /* ---- prove (src/prover/prove.rs) ---------------------------------------- */
 /* Batch of N independent equations of one type and shape over the shared CRS.
  * xcoms/ycoms may be NULL (prove only) or receive the commitments
- * (commit_and_prove).  pi: N*kx Com2, theta: N*ky Com1. */
+ * (commit_and_prove).  pi: N*kx Com2, theta: N*ky Com1.
+ * Host-pointer forms (no _dev suffix; what a Rust caller of prove.rs:29-52 / verifier.rs:18-21 holds): the arrays are
+ * staged through a grow-only PINNED buffer by a few memcpy workers, uploaded on a copy stream array by array, and the
+ * kernels wait only for the arrays they read (scalars before the preparation kernel, G1 arguments before the G1 side,
+ * G2 arguments before the G2 side / the Miller loop), so most of the transfer runs under kernels; outputs come back
+ * the same way.  Per context: pinned staging = the call's input + output bytes (0.83 GB at 2^16 PPE 4x4),
+ * device staging the same, plus the engine's scratch (section "memory" of DESIGN.md). */
 int gs_prove_batch_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const void* X, const void* Y, const void* A,
                        const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
                        void* ycoms, void* pi, void* theta);
@@ -158,6 +167,41 @@ int gs_verify_statement_dev(gs_ctx*, int equ_type, size_t E, int m, int n, const
 int gs_verify_statement(gs_ctx*, int equ_type, size_t E, int m, int n, const void* A, const void* B, const void* Gamma,
                         const void* target, const void* xcoms, const void* ycoms, const void* pi, const void* theta,
                         uint8_t* ok);
+/* ---- mixed batches and mixed-type Statements: several sub-batches in ONE call ------------------------------------
+ * configs[2] of the baseline mixes PPE, MSMEG1 and MSMEG2 equations; the reference's Statement is a list of equations
+ * of ANY type over one list of variables (src/statement.rs:24-28,109).  A part is a homogeneous sub-batch (type, N, m,
+ * n and the arrays of gs_prove_batch / gs_verify_batch for it); parts may differ in type AND shape.  All parts are in
+ * flight together (each on a child context: own stream and scratch, the parent's CRS tables), so a mixed batch fills
+ * the chip like a homogeneous batch of its total size; outputs are byte-identical to one gs_prove_batch /
+ * gs_verify_batch call per part.
+ * shared_vars != 0 makes the part a Statement's: X, Y, R, S hold ONE copy (m / n entries) that all N equations of the
+ * part use, xcoms / ycoms are the statement's commitments (m / n entries; prove writes them when non-NULL -- pass them
+ * with ONE of the parts that use a variable group and NULL with the others -- verify reads them), i.e. exactly
+ * gs_prove_statement / gs_verify_statement per part.  A mixed-type Statement over G1 variables Xg, G2 variables Yg
+ * and scalar variables xs, ys is then one call with the parts PPE (Xg, Yg), MSMEG1 (Xg, ys), MSMEG2 (xs, Yg) and
+ * QuadEqu (xs, ys) pointing at the shared groups.  At most GS_MIXED_MAX parts per call. */
+#define GS_MIXED_MAX 8
+typedef struct {
+  int equ_type;
+  size_t N;
+  int m, n;
+  const void *X, *Y, *A, *B, *Gamma, *R, *S, *T;
+  void *xcoms, *ycoms, *pi, *theta;
+  int shared_vars;
+} gs_prove_part;
+typedef struct {
+  int equ_type;
+  size_t N;
+  int m, n;
+  const void *A, *B, *Gamma, *target, *xcoms, *ycoms, *pi, *theta;
+  uint8_t* ok;
+  int shared_vars;
+} gs_verify_part;
+int gs_prove_mixed_dev(gs_ctx*, int nparts, const gs_prove_part* parts);
+int gs_prove_mixed(gs_ctx*, int nparts, const gs_prove_part* parts);
+int gs_verify_mixed_dev(gs_ctx*, int nparts, const gs_verify_part* parts);
+int gs_verify_mixed(gs_ctx*, int nparts, const gs_verify_part* parts);
+
 /* Batched pairing-product check: random linear combination of all 4N cell
  * equations with caller-supplied 64-bit exponents rho[N][4] (device/host u64).
  * RHO CONTRACT (soundness rests on it): every rho is drawn from a CSPRNG, fresh for every call, NON-ZERO, secret
@@ -179,27 +223,43 @@ int gs_verify_batch_rlc_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const
 int gs_verify_batch_rlc(gs_ctx*, int equ_type, size_t N, int m, int n, const void* A, const void* B,
                         const void* Gamma, const void* target, const void* xcoms, const void* ycoms, const void* pi,
                         const void* theta, const uint64_t* rho, void* acc_gt, uint8_t* ok_all);
-/* product of `count` GT accumulators (host), final exponentiation, == 1 ? */
+/* product of `count` GT accumulator pairs (host), final exponentiation, FE(prod acc[0]) == prod acc[1] ? */
 int gs_gt_finalize(gs_ctx*, size_t count, const void* accs_gt_host, uint8_t* ok_all);
+/* the same with the pairs in this context's device memory (e.g. the receive buffer of an all-gather); ok_all on the host */
+int gs_gt_finalize_dev(gs_ctx*, size_t count, const void* accs_gt_dev, uint8_t* ok_all);
 
 /* ---- several GPUs of one node ----------------------------------------------------------
- * gs_ctx_create_multi owns one context (stream, scratch, CRS tables) per listed device ordinal.  A batch is cut into
- * contiguous blocks of equation indices, block i on devices[i] (sizes differ by at most one: gs_multi_shard); every
- * block runs the single-device entry point of the same name on its own host thread.  Host pointers, whole batch in,
- * whole batch out, identical bytes to a single-device run.  Prove and exact verify use no collective.  The batched
- * verifier all-gathers the per-device accumulator pairs (2 GT each) over RCCL, multiplies them in device order and runs
- * ONE final exponentiation: the verdict for the union of the blocks (same rho contract as gs_verify_batch_rlc; rho is
- * indexed by GLOBAL equation number).  acc_pairs (may be NULL) receives the ndev gathered pairs.  RCCL is bound at run
- * time (dlopen of librccl.so, preferring a copy already in the process); only gs_multi_verify_batch_rlc needs it. */
+ * gs_ctx_create_multi owns one SHARD per listed device ordinal: a context (stream, scratch; CRS tables shared per
+ * device) and a persistent host thread bound to that device.  A batch is cut into contiguous blocks of equation
+ * indices, block i on shard i (sizes differ by at most one: gs_multi_shard); every block runs the single-device entry
+ * point of the same name on its shard's thread.  Identical bytes to a single-device run.  Prove and exact verify use
+ * no collective.  The batched verifier's per-shard accumulator pairs (2 GT each) are written into per-shard exchange
+ * buffers on their devices, all-gathered (RCCL over xGMI when the shards sit on distinct devices; device-to-device /
+ * peer copies for one shard, shards sharing a device or a missing librccl: gs_multi_exchange_note says which),
+ * cross-checked, multiplied in shard order on device 0 and finished with ONE final exponentiation: the verdict for the
+ * union of the blocks (same rho contract as gs_verify_batch_rlc; rho is indexed by GLOBAL equation number).
+ * acc_pairs (host, may be NULL) receives the ndev gathered pairs.  RCCL is bound at run time (dlopen of librccl.so,
+ * preferring a copy already in the process).
+ *   host-pointer family: whole batch in, whole batch out; every shard stages its block through its context's pinned
+ *     pipeline (see gs_prove_batch).
+ *   _dev family: arrays of ndev DEVICE pointers, entry i = shard i's block already resident on devices[i] (what a
+ *     caller that produced the data on the GPUs holds); nothing crosses PCIe; calls return once every shard has
+ *     enqueued its kernels, gs_multi_sync joins.  (gs_multi_verify_batch_rlc_dev returns the verdict, so it joins.)
+ * GS_MULTI_SHARED_DEVICES lets several shards name the SAME ordinal: the split, offsets, empty blocks and the pair
+ * exchange then run on one GPU exactly as they would on eight (how tests exercise ndev > 1 on a one-GPU box). */
 typedef struct gs_multi gs_multi;
+enum { GS_MULTI_SHARED_DEVICES = 1 };
 int gs_ctx_create_multi(int curve_id, const int* device_ordinals, int ndev, gs_multi** out);
+int gs_ctx_create_multi_ex(int curve_id, const int* device_ordinals, int ndev, int flags, gs_multi** out);
 void gs_multi_destroy(gs_multi*);
 int gs_multi_ndev(gs_multi*);
-gs_ctx* gs_multi_ctx(gs_multi*, int i);                      /* devices[i]'s context, e.g. for gs_set_option */
+gs_ctx* gs_multi_ctx(gs_multi*, int i);                      /* shard i's context, e.g. for gs_set_option */
 const char* gs_multi_last_error(gs_multi*);
 int gs_multi_uses_rccl(gs_multi*);                           /* 1 once the RCCL communicators exist */
-int gs_multi_shard(gs_multi*, size_t N, int i, size_t* lo, size_t* hi); /* block [lo, hi) of devices[i] */
+const char* gs_multi_exchange_note(gs_multi*);               /* how the accumulator pairs travel (and why not RCCL) */
+int gs_multi_shard(gs_multi*, size_t N, int i, size_t* lo, size_t* hi); /* block [lo, hi) of shard i */
 int gs_multi_set_crs(gs_multi*, const void* crs_host);
+int gs_multi_sync(gs_multi*);                                /* drain every shard's stream */
 int gs_multi_prove_batch(gs_multi*, int equ_type, size_t N, int m, int n, const void* X, const void* Y, const void* A,
                          const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
                          void* ycoms, void* pi, void* theta);
@@ -210,6 +270,21 @@ int gs_multi_verify_batch_rlc(gs_multi*, int equ_type, size_t N, int m, int n, c
                               const void* Gamma, const void* target, const void* xcoms, const void* ycoms,
                               const void* pi, const void* theta, const uint64_t* rho, void* acc_pairs_gt,
                               uint8_t* ok_all);
+int gs_multi_prove_batch_dev(gs_multi*, int equ_type, size_t N, int m, int n, const void* const* X,
+                             const void* const* Y, const void* const* A, const void* const* B,
+                             const void* const* Gamma, const void* const* R, const void* const* S,
+                             const void* const* T, void* const* xcoms, void* const* ycoms, void* const* pi,
+                             void* const* theta);
+int gs_multi_verify_batch_dev(gs_multi*, int equ_type, size_t N, int m, int n, const void* const* A,
+                              const void* const* B, const void* const* Gamma, const void* const* target,
+                              const void* const* xcoms, const void* const* ycoms, const void* const* pi,
+                              const void* const* theta, uint8_t* const* ok);
+/* rho[i]: shard i's exponents on its device, 4 per equation of ITS block */
+int gs_multi_verify_batch_rlc_dev(gs_multi*, int equ_type, size_t N, int m, int n, const void* const* A,
+                                  const void* const* B, const void* const* Gamma, const void* const* target,
+                                  const void* const* xcoms, const void* const* ycoms, const void* const* pi,
+                                  const void* const* theta, const uint64_t* const* rho, void* acc_pairs_gt_host,
+                                  uint8_t* ok_all);
 
 /* ---- L2 parity hooks (host pointers) ------------------------------------- */
 /* out[i] = sum_k lhs[i][k] * col[k]       (data_structures.rs:696-742) */

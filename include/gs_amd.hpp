@@ -641,6 +641,11 @@ struct MultiCtx {
     if (m == 0 || n == 0) throw Panic("index out of bounds: empty commitment list");
     Bytes A, B, G, tg, xc, yc, pi, th;
     auto app = [](Bytes& d, const Bytes& s) { d.insert(d.end(), s.begin(), s.end()); };
+    const EquType ty = equs[0].get_type();
+    const bool xs = ty == EquType::MultiScalarG2 || ty == EquType::Quadratic, ys = ty == EquType::MultiScalarG1 || ty == EquType::Quadratic;
+    const size_t sx = xs ? sz[1] : sz[2], sy = ys ? sz[1] : sz[3];
+    const size_t tsz = ty == EquType::PairingProduct ? sz[4] : ty == EquType::MultiScalarG1 ? sz[2]
+                       : ty == EquType::MultiScalarG2 ? sz[3] : sz[1];
     for (size_t i = 0; i < N; i++) {
       const Equ& e = equs[i];
       const CProof& p = proofs[i];
@@ -650,6 +655,9 @@ struct MultiCtx {
       e.check_statement_shape(m, n);
       assert_eq(p.equ_proofs[0].pi.size(), Equ::KX, "pi.len()");
       assert_eq(p.equ_proofs[0].theta.size(), Equ::KY, "theta.len()");
+      // per equation, as Equation::verify does: ONE short target or constant would shift every later equation's
+      // operands and let the C ABI read past the end of the buffers
+      assert_eq(e.target.v.size(), tsz, "target size");
       app(A, cat(e.a_consts));
       app(B, cat(e.b_consts));
       app(G, cat(e.gamma));
@@ -664,7 +672,9 @@ struct MultiCtx {
     assert_eq(yc.size(), N * n * 2 * sz[3], "ycoms bytes");
     assert_eq(pi.size(), N * Equ::KX * 2 * sz[3], "pi bytes");
     assert_eq(th.size(), N * Equ::KY * 2 * sz[2], "theta bytes");
-    assert_eq(tg.size() % N, 0, "target bytes");
+    assert_eq(A.size(), N * n * sx, "a_consts bytes");
+    assert_eq(B.size(), N * m * sy, "b_consts bytes");
+    assert_eq(tg.size(), N * tsz, "target bytes");
     std::vector<uint8_t> ok(N, 0);
     chk(gs_multi_verify_batch(h, (int)equs[0].get_type(), N, (int)m, (int)n, A.data(), B.data(), G.data(), tg.data(),
                               xc.data(), yc.data(), pi.data(), th.data(), ok.data()));

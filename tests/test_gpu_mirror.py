@@ -205,6 +205,31 @@ def test_statement_with_shared_commitments(setup, idx):
     assert verdicts == each and verdicts[0] is True and verdicts[1] is False
     # first equation's proof bytes are the golden fixture's
     assert [c.com2_dec(v) for v in proof.equ_proofs[0].pi] == case["pi"]
+    # EVERY equation against the C oracle (oracle/gs_ref.c: ref_commit_and_prove with the same X, Y, R, S and that
+    # equation's A, B, Gamma, T gives the shared commitments and its pi / theta; ref_verify its verdict)
+    import os
+    import sys
+
+    from gsutil import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gs_ref_py as ref
+
+    g = c.golden["crs"]
+    flat_crs = np.concatenate([c.com1(g["u"][0]), c.com1(g["u"][1]), c.com2(g["v"][0]), c.com2(g["v"][1]), c.g1(g["g1"]),
+                               c.g2(g["g2"]), c.f12(g["gt"])])
+    cat = lambda xs: np.concatenate([np.asarray(x, dtype=np.uint64).reshape(-1) for x in xs])
+    mat = lambda m_: cat([e for row in m_ for e in row])
+    ty, m, n = case["type"], len(xvars), len(yvars)
+    for e, pf, v in zip((equ0, equ1, equ2), proof.equ_proofs, verdicts):
+        want = ref.commit_and_prove("bls12_381", ty, m, n, cat(xvars), cat(yvars), cat(e.a_consts), cat(e.b_consts),
+                                    mat(e.gamma), mat(proof.xcoms.rand), mat(proof.ycoms.rand), mat(pf.rand), flat_crs)
+        assert (want["xcoms"].view(np.uint64) == cat(proof.xcoms.coms)).all()
+        assert (want["ycoms"].view(np.uint64) == cat(proof.ycoms.coms)).all()
+        assert (want["pi"].view(np.uint64) == cat(pf.pi)).all() and (want["theta"].view(np.uint64) == cat(pf.theta)).all()
+        ov = ref.verify("bls12_381", ty, m, n, cat(e.a_consts), cat(e.b_consts), mat(e.gamma),
+                        np.asarray(e.target, dtype=np.uint64).reshape(-1), want["xcoms"], want["ycoms"], want["pi"],
+                        want["theta"], flat_crs)
+        assert bool(ov) == v
 
 
 def _mat_same(a, b):

@@ -1,6 +1,10 @@
-"""The multi-GPU layer of the C ABI (gs_ctx_create_multi, include/gs_amd.h) on the one GPU a test box has: ndev = 1
-through the multi entry points must give the single-device bytes, the block partition must tile the batch, and the
-batched verifier's accumulator exchange must really go through RCCL (one rank here; the 8-GPU run is the driver's).
+"""The multi-GPU layer of the C ABI (gs_ctx_create_multi, include/gs_amd.h) on the one GPU a test box has.
+  * ndev = 1 through the multi entry points gives the single-device bytes;
+  * GS_MULTI_SHARED_DEVICES puts 2, 3 and 8 SHARDS on that one GPU, so the block partition with lo > 0, every
+    type-dependent offset of the host entry points, empty blocks (N < ndev), the per-shard device-pointer family and the
+    accumulator-pair exchange + shard-order product of the batched verifier all execute here, before an 8-GPU node
+    runs them: same bytes and verdicts as the single-device engine, a corrupted proof in the LAST shard found by both
+    verifiers, rho indexed globally.
 Unmeasured on multi-GPU hardware until a SCALE line exists."""
 import numpy as np
 import pytest
@@ -32,7 +36,7 @@ def test_multi_entry_matches_single_device_bytes():
         assert ok.all()
         rho = np.frombuffer(np.random.default_rng(ty).bytes(N * 32), dtype=np.uint64) | np.uint64(1)
         v, pairs = me.verify_batch_rlc(ty, N, m, n, A, B, G, tgt, got["xcoms"], got["ycoms"], got["pi"], got["theta"], rho)
-        assert v == 1 and me.uses_rccl(), "the accumulator pairs must travel through RCCL"
+        assert v == 1 and not me.uses_rccl() and "one shard" in me.exchange_note()  # nothing to exchange with one shard
         # same accumulator pair as the single-device batched verifier with the same rho
         v1, acc1 = eng.verify_batch_rlc(ty, N, m, n, A, B, G, tgt, got["xcoms"], got["ycoms"], got["pi"], got["theta"], rho)
         assert v1 == 1 and (acc1 == pairs).all()
@@ -54,7 +58,7 @@ def test_multi_rejects_bad_device_lists_and_shapes():
     lib = gs.load_library()
     h = ctypes.c_void_p()
     two = (ctypes.c_int * 2)(0, 0)
-    assert lib.gs_ctx_create_multi(0, two, 2, ctypes.byref(h)) == 3       # the same device twice
+    assert lib.gs_ctx_create_multi(0, two, 2, ctypes.byref(h)) == 3       # the same device twice (without the flag)
     assert lib.gs_ctx_create_multi(0, two, 0, ctypes.byref(h)) == 3       # no device
     far = (ctypes.c_int * 1)(99)
     assert lib.gs_ctx_create_multi(0, far, 1, ctypes.byref(h)) == 2       # GS_ERR_DEVICE
@@ -63,4 +67,104 @@ def test_multi_rejects_bad_device_lists_and_shapes():
         z = np.zeros(8, dtype=np.uint8)
         me.verify_batch(0, 1, 1, 1, z, z, z, z, z, z, z, z)
     assert ei.value.code == 1
+    me.close()
+
+
+@pytest.mark.parametrize("ndev,N", [(2, 37), (3, 64), (8, 5)])
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])
+def test_split_over_several_shards_of_one_gpu(cname, cid, ndev, N):
+    import torch
+
+    import groth_sahai_rs_amd as gs
+    from groth_sahai_rs_amd.workload import Workload
+
+    m, n = 3, 2
+    host = lambda t: t.cpu().numpy()
+    for ty in (0, 1, 2, 3):
+        eng = gs.Engine(cid, 0)
+        wl = Workload(eng, ty=ty, N=N, m=m, n=n, seed=8900 + 10 * ndev + ty, corrupt_every=0)
+        wl.prove()
+        eng.sync()
+        names = ("X", "Y", "A", "B", "Gamma", "R", "S", "T", "target")
+        dev = {k: getattr(wl, k) for k in names}
+        X, Y, A, B, G, R, S, T, tgt = [host(dev[k]) for k in names]
+        want = {k: host(getattr(wl, k)) for k in ("xcoms", "ycoms", "pi", "theta")}
+        me = gs.MultiEngine(cid, [0] * ndev, shared_devices=True)
+        me.set_crs(wl.crs)
+        blocks = [me.shard(N, i) for i in range(ndev)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == N and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
+        assert (N >= ndev) or any(h == l for l, h in blocks)  # 5 equations on 8 shards: empty blocks
+        # ---- host-pointer family: whole batch in, whole batch out
+        got = me.prove_batch(ty, N, m, n, X, Y, A, B, G, R, S, T)
+        for k in want:
+            assert (got[k] == want[k]).all(), (ty, k)
+        args = (A, B, G, tgt, got["xcoms"], got["ycoms"])
+        assert me.verify_batch(ty, N, m, n, *args, got["pi"], got["theta"]).all()
+        bad = got["pi"].copy()
+        bad[(N - 1) * (len(bad) // N) + 5] ^= 4  # the LAST equation: it lives in the last non-empty shard
+        ok_multi = me.verify_batch(ty, N, m, n, *args, bad, got["theta"])
+        ok_single = eng.verify_batch(ty, N, m, n, *args, bad, got["theta"])
+        assert (ok_multi == ok_single).all() and ok_multi[:-1].all() and ok_multi[-1] == 0
+        rho = np.frombuffer(np.random.default_rng(100 + ty).bytes(N * 32), dtype=np.uint64) | np.uint64(1)
+        v, pairs = me.verify_batch_rlc(ty, N, m, n, *args, got["pi"], got["theta"], rho)
+        assert v == 1 and "share a device" in me.exchange_note()
+        pairs = pairs.reshape(ndev, -1)
+        one = None
+        for i, (lo, hi) in enumerate(blocks):  # every shard's pair = the single-device pair of ITS block with ITS rho
+            if hi == lo:
+                one = pairs[i] if one is None else one
+                assert (pairs[i] == one).all() and (pairs[i][:eng.GT] == pairs[i][eng.GT:]).all()  # (1, 1)
+                continue
+            sl = lambda a, per: a[lo * per:hi * per]
+            per = lambda a: len(a) // N
+            v1, acc1 = eng.verify_batch_rlc(ty, hi - lo, m, n, sl(A, per(A)), sl(B, per(B)), sl(G, per(G)),
+                                            sl(tgt, per(tgt)), sl(got["xcoms"], per(got["xcoms"])),
+                                            sl(got["ycoms"], per(got["ycoms"])), sl(got["pi"], per(got["pi"])),
+                                            sl(got["theta"], per(got["theta"])), rho[4 * lo:4 * hi])
+            assert v1 == 1 and (acc1 == pairs[i]).all(), (ty, i)
+        assert eng.gt_finalize(pairs.reshape(-1)) == 1
+        v, _ = me.verify_batch_rlc(ty, N, m, n, *args, bad, got["theta"], rho)
+        assert v == 0
+        # ---- device-pointer family: shard i's block already on its device
+        cut = lambda t, i: t[blocks[i][0] * (t.numel() // N):blocks[i][1] * (t.numel() // N)].clone()
+        per_shard = lambda t: [cut(t, i) for i in range(ndev)]
+        outs = {k: [torch.zeros_like(cut(getattr(wl, k), i)) for i in range(ndev)] for k in ("xcoms", "ycoms", "pi", "theta")}
+        ins = {k: per_shard(dev[k]) for k in names}
+        me.prove_batch_dev(ty, N, m, n, ins["X"], ins["Y"], ins["A"], ins["B"], ins["Gamma"], ins["R"], ins["S"], ins["T"],
+                           outs["xcoms"], outs["ycoms"], outs["pi"], outs["theta"])
+        me.sync()
+        for k in want:
+            assert (np.concatenate([host(t) for t in outs[k]]) == want[k]).all(), (ty, k, "dev")
+        okd = [torch.zeros(hi - lo, dtype=torch.uint8, device="cuda:0") for lo, hi in blocks]
+        me.verify_batch_dev(ty, N, m, n, ins["A"], ins["B"], ins["Gamma"], ins["target"], outs["xcoms"], outs["ycoms"],
+                            outs["pi"], outs["theta"], okd)
+        me.sync()
+        assert np.concatenate([host(t) for t in okd]).all()
+        rho_t = torch.from_numpy(rho.view(np.int64)).to("cuda:0")
+        rho_sh = [rho_t[4 * lo:4 * hi].clone() for lo, hi in blocks]
+        vd, pairs_d = me.verify_batch_rlc_dev(ty, N, m, n, ins["A"], ins["B"], ins["Gamma"], ins["target"], outs["xcoms"],
+                                              outs["ycoms"], outs["pi"], outs["theta"], rho_sh)
+        assert vd == 1 and (pairs_d.reshape(ndev, -1) == pairs).all()  # the same pairs as the host family
+        last = [i for i, (lo, hi) in enumerate(blocks) if hi > lo][-1]
+        outs["pi"][last][-7] ^= 2  # a proof of the last non-empty shard
+        vd, _ = me.verify_batch_rlc_dev(ty, N, m, n, ins["A"], ins["B"], ins["Gamma"], ins["target"], outs["xcoms"],
+                                        outs["ycoms"], outs["pi"], outs["theta"], rho_sh)
+        assert vd == 0
+        me.close()
+        eng.close()
+
+
+def test_multi_rlc_rejects_null_rho():
+    import ctypes
+
+    import groth_sahai_rs_amd as gs
+
+    me = gs.MultiEngine(0, [0, 0], shared_devices=True)
+    z = np.zeros(16, dtype=np.uint8)
+    ok = np.zeros(1, dtype=np.uint8)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    rc = me.lib.gs_multi_verify_batch_rlc(me.h, 0, ctypes.c_size_t(4), 1, 1, p(z), p(z), p(z), p(z), p(z), p(z), p(z), p(z),
+                                          ctypes.c_void_p(0), ctypes.c_void_p(0), p(ok))
+    assert rc == 3 and "rho" in me.lib.gs_multi_last_error(me.h).decode()
     me.close()

@@ -29,12 +29,22 @@ SHAPES = {
                                    overlap=0),
     "twin12_straus8x2_lane": dict(red_k=4, miller_twin=1, miller_ch=12, var_tm=8, var_mo=2, var_w=4, coop_fe=0, line_tables=1,
                                  overlap=0),
+    # the twin task list on PAIRS of lanes, one accumulator each, lines exchanged through LDS (2) or DPP (3):
+    # k_miller_pair; 12 triples per task (6 twist points per lane), 5 (odd: lane 1 idles in the last round, no tables)
+    # and 3 with tables (one stepping point against two)
+    "pair12_straus8x2w5_lane": dict(red_k=4, miller_twin=2, miller_ch=12, var_tm=8, var_mo=2, var_w=5, coop_fe=0,
+                                   line_tables=1, overlap=0),
+    "pair5dpp_straus4_coop_notab": dict(red_k=2, miller_twin=3, miller_ch=5, var_tm=4, var_mo=1, var_w=4, coop_fe=2,
+                                       line_tables=0, overlap=0),
+    "pair3_straus2_lane_overlap": dict(red_k=1, miller_twin=2, miller_ch=3, var_tm=2, var_mo=1, var_w=4, coop_fe=0,
+                                       line_tables=1, overlap=1),
 }
+MILLER_KERNEL = {0: "k_miller", 1: "k_miller.twin", 2: "k_miller.pair", 3: "k_miller.pairdpp"}
 
 
 def expected_kernels(ty, m, n, o):
     xg, yg = ty in (0, 1), ty in (0, 2)
-    ex = ["k_miller.twin" if o["miller_twin"] else "k_miller", "k_final.coop" if o["coop_fe"] == 2 else "k_final"]
+    ex = [MILLER_KERNEL[o["miller_twin"]], "k_final.coop" if o["coop_fe"] == 2 else "k_final"]
 
     def var_name(terms, tag):  # what pick_tm's balanced group size selects (csrc/gs_amd.hip)
         tm = o["var_tm"]
@@ -87,7 +97,7 @@ def test_option_values_are_validated():
 
     eng = gs.Engine(0, 0)
     try:
-        for key, bad in (("no_such_option", 1), ("miller_ch", 13), ("miller_twin", 2), ("var_tm", 9), ("var_mo", 3),
+        for key, bad in (("no_such_option", 1), ("miller_ch", 13), ("miller_twin", 4), ("var_tm", 9), ("var_mo", 3),
                          ("var_w", 6), ("red_k", 3), ("var_ws_lanes", 100), ("coop_fe", 3)):
             with pytest.raises(gs.GsError):
                 eng.set_option(key, bad)

@@ -254,6 +254,7 @@ template <class C> struct Twin {
       multi_miller(f, P, Q, 1, T, live);
     }
     long c0 = fq28_mul_counter().load();
+    long m0 = fq28_mad_counter().load();
     switch (op) {
       case 0: jac_smul_any<C>(J1, P[0], k[0]); break;
       case 1: jac_smul_any<C>(J2, Q[0], k[0]); break;
@@ -321,6 +322,7 @@ template <class C> struct Twin {
         }
         Proj2<C> T[8];
         c0 = fq28_mul_counter().load();
+        m0 = fq28_mad_counter().load();
         if (op == 15) {
           bool live[8];
           multi_miller(g, P, Q, nt, T, live, fx);
@@ -330,6 +332,7 @@ template <class C> struct Twin {
           multi_miller2(g, g1v, P, P, Q, nt, T, live, fx);
         }
         long v = fq28_mul_counter().load() - c0;
+        last_mads() = fq28_mad_counter().load() - m0;
         delete[] tabs;
         return v;
       }
@@ -339,12 +342,20 @@ template <class C> struct Twin {
         uint8_t in[12 * NB], out[3 * 12 * NB];
         f12_to_boundary<C>((BFq<C>*)in, f);
         c0 = fq28_mul_counter().load();
+        m0 = fq28_mad_counter().load();
         coop(1, in, out);
+        last_mads() = fq28_mad_counter().load() - m0 - (3 * 12 + 12) * 2L * C::L * C::L;
         return fq28_mul_counter().load() - c0 - 3 * 12 - 12;  // minus the boundary conversions of this harness
       }
       default: break;
     }
+    last_mads() = fq28_mad_counter().load() - m0;
     return fq28_mul_counter().load() - c0;
+  }
+  // multiply-add instructions the device executes for the primitive last counted by opcount (fq28_mad_counter)
+  static long& last_mads() {
+    static long v = 0;
+    return v;
   }
   // the same with the pairs selected by `mask` reading a precomputed line table of their G2 argument
   static void multi_pairing_fixed(int np, const uint8_t* ps, const uint8_t* qs, unsigned mask, uint8_t* o, int twin_mode) {
@@ -424,6 +435,7 @@ extern "C" long twin_fq_mul_count(int reset) {
   long twin_opcount_##SUF(int op, int nt, const uint8_t* g1, const uint8_t* g2, const uint32_t* k) {              \
     return Twin<CURVE>::opcount(op, nt, g1, g2, k);                                                                \
   }                                                                                                               \
+  long twin_last_mads_##SUF() { return Twin<CURVE>::last_mads(); }                                                 \
   void twin_wire_enc_##SUF(int g, int c, const uint8_t* pt, uint8_t* out) { Twin<CURVE>::wire_enc(g, c, pt, out); }  \
   int twin_wire_dec_##SUF(int g, int c, int v, const uint8_t* in, uint8_t* pt) {                                  \
     return Twin<CURVE>::wire_dec(g, c, v, in, pt);                                                                 \
