@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -113,11 +114,15 @@ struct gs_ctx {
   void* pin = nullptr;
   size_t pin_cap = 0;
   hipEvent_t pev[16] = {nullptr};
-  // mixed batches (gs_prove_mixed / gs_verify_mixed): sub-batches run on child contexts (own stream and scratch,
-  // the parent's CRS tables) so that their kernels share the chip
-  std::vector<gs_ctx*> kids;
-  hipEvent_t kid_ev[2] = {nullptr, nullptr};
-  bool own_stream = false;  // a child's stream belongs to it
+  // mixed calls: launches are recorded per part and merged (launch_seg / replay); scratch buffers get a per-part tag;
+  // the lane-shape planners see the batch size the merged launches will have
+  struct Recorder* rec = nullptr;
+  int mixed_merge = -1;  // -1 planned (merge while the parts cannot fill the chip on their own), 0 never, 1 always
+  int scratch_tag = 0;
+  size_t fill_n = 0;
+  hipStream_t copy_stream2 = nullptr, copy_out_stream = nullptr, copy_out_stream2 = nullptr;  // two per direction
+  hipEvent_t pev2[16] = {nullptr};
+  hipEvent_t pev_ready = nullptr;
 };
 
 static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -136,9 +141,9 @@ static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess
     if (e_ != hipSuccess) return fail(ctx, GS_ERR_DEVICE, #call, e_); \
   } while (0)
 
-#define RC(x)                 \
-  do {                        \
-    int rc_ = (x);            \
+#define RC(...)                   \
+  do {                            \
+    int rc_ = (__VA_ARGS__);      \
     if (rc_ != GS_OK) return rc_; \
   } while (0)
 
@@ -161,6 +166,11 @@ static int ensure(gs_ctx* c, DevBuf& b, size_t bytes) {
   return GS_OK;
 }
 static int scratch(gs_ctx* c, const char* name, size_t bytes, void** out) {
+  char tagged[96];
+  if (c->scratch_tag) {  // a part of a mixed call: its buffers are live next to the other parts'
+    snprintf(tagged, sizeof tagged, "m%d:%s", c->scratch_tag, name);
+    name = tagged;
+  }
   DevBuf& b = c->scratch[name];
   int rc = ensure(c, b, bytes);
   *out = b.p;
@@ -283,13 +293,21 @@ struct HostPipe {
   };
   gs_ctx* c;
   Arr arr[16];
+  hipEvent_t ev1[16] = {nullptr}, ev2[16] = {nullptr};
+  int out_order[16], n_out = 0;  // output arrays in the order their D2H went out (= the order they arrive)
   int n = 0;
-  bool begun = false;
+  bool trace = false;
+  int split = 2;  // DMA transfers per array and direction (two copy streams: two SDMA engines)
+  std::chrono::steady_clock::time_point t0;
   explicit HostPipe(gs_ctx* ctx) : c(ctx) {}
   ~HostPipe() {
     for (int i = 0; i < n; i++) CopyPool::wait(&arr[i].left);  // no worker may still touch the caller's memory
+    for (int i = 0; i < 16; i++)
+      for (hipEvent_t ev : {ev1[i], ev2[i]})
+        if (ev) hipEventDestroy(ev);
     if (c->pipe == this) c->pipe = nullptr;
   }
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
   // declare array `i` (slots are fixed per entry point: the need() masks name them); null / empty arrays stay absent
   int in(int i, const void* h, size_t bytes) {
     if (h && bytes) arr[i].hin = h, arr[i].bytes = bytes;
@@ -302,39 +320,74 @@ struct HostPipe {
     return GS_OK;
   }
   void* dev(int i) const { return arr[i].d; }
-  // device slots, pinned staging, workers; then the staging copies start, inputs in the order `order` lists them
-  int begin(const int* order, int norder) {
-    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < n; i++)
-      if (!c->pev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->pev[i], hipEventDisableTiming));
+  // bytes of pinned staging this call needs (every declared array, 256-byte aligned)
+  size_t layout() {
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+      if (!arr[i].bytes) continue;
+      arr[i].off = total;
+      total += (arr[i].bytes + 255) & ~(size_t)255;
+    }
+    return total;
+  }
+  // the context's grow-only pinned buffer holds at least `bytes` (never call between begin() and finish() of a pipe
+  // that uses it: growing moves it)
+  static int pin_reserve(gs_ctx* c, size_t bytes) {
+    if (bytes <= c->pin_cap) return GS_OK;
+    if (c->pin) hipHostFree(c->pin);
+    c->pin = nullptr;
+    c->pin_cap = 0;
+    hipError_t e = hipHostMalloc(&c->pin, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, GS_ERR_ALLOC, "hipHostMalloc (pinned staging)", e);
+    c->pin_cap = bytes;
+    return GS_OK;
+  }
+  // device slots, workers; then the staging copies start, inputs in the order `order` lists them.  `base`: where this
+  // pipe's region of the pinned buffer begins (several pipes of one mixed call share the buffer)
+  int begin(const int* order, int norder, size_t base = 0, bool reserve = true) {
+    t0 = std::chrono::steady_clock::now();
+    trace = getenv("GS_PIPE_TRACE") != nullptr;
+    if (const char* e = getenv("GS_COPY_SPLIT")) split = std::max(1, std::min(2, atoi(e)));
+    for (hipStream_t* st : {&c->copy_stream, &c->copy_stream2, &c->copy_out_stream, &c->copy_out_stream2})
+      if (!*st) HIPCHK(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    if (!c->pev_ready) HIPCHK(c, hipEventCreateWithFlags(&c->pev_ready, hipEventDisableTiming));
     if (!c->pool) {
       int nt = 4;
       if (const char* e = getenv("GS_COPY_THREADS")) nt = std::max(1, std::min(32, atoi(e)));
       c->pool = new CopyPool(nt);
     }
-    size_t total = 0;
+    const size_t total = layout();
+    if (reserve) RC(pin_reserve(c, base + total));
     for (int i = 0; i < n; i++) {
       if (!arr[i].bytes) continue;
       char name[32];
       snprintf(name, sizeof name, "stage.%d", i);
       RC(scratch(c, name, arr[i].bytes, &arr[i].d));
-      arr[i].off = total;
-      total += (arr[i].bytes + 255) & ~(size_t)255;
-    }
-    if (total > c->pin_cap) {
-      if (c->pin) hipHostFree(c->pin);
-      c->pin = nullptr;
-      c->pin_cap = 0;
-      hipError_t e = hipHostMalloc(&c->pin, total, hipHostMallocDefault);
-      if (e != hipSuccess) return fail(c, GS_ERR_ALLOC, "hipHostMalloc (pinned staging)", e);
-      c->pin_cap = total;
+      arr[i].off += base;
+      // events are per (pipe, array): a mixed call has several pipes in flight
+      for (hipEvent_t* ev : {&ev1[i], &ev2[i]}) HIPCHK(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     for (int k = 0; k < norder; k++) {
       Arr& a = arr[order[k]];
       if (a.hin) c->pool->submit((uint8_t*)c->pin + a.off, a.hin, a.bytes, &a.left);
     }
-    begun = true;
     c->pipe = this;
+    if (trace) fprintf(stderr, "[pipe] %7.2f ms begin done (%zu bytes of staging)\n", ms(), total);
+    return GS_OK;
+  }
+  // one array across PCIe, in `split` pieces on as many copy streams; ev is recorded (on s0) behind all of them
+  int xfer(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s0, hipStream_t s1, hipEvent_t ev,
+           hipEvent_t ev_b) {
+    if (split < 2 || bytes < ((size_t)4 << 20)) {
+      HIPCHK(c, hipMemcpyAsync(dst, src, bytes, kind, s0));
+    } else {
+      size_t h = (bytes / 2 + 255) & ~(size_t)255;
+      HIPCHK(c, hipMemcpyAsync(dst, src, h, kind, s0));
+      HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + h, (const uint8_t*)src + h, bytes - h, kind, s1));
+      HIPCHK(c, hipEventRecord(ev_b, s1));
+      HIPCHK(c, hipStreamWaitEvent(s0, ev_b, 0));
+    }
+    HIPCHK(c, hipEventRecord(ev, s0));
     return GS_OK;
   }
   // the kernels about to be enqueued read the input arrays in `mask`: their uploads go out (if they have not yet)
@@ -345,40 +398,75 @@ struct HostPipe {
       Arr& a = arr[i];
       if (!((mask >> i) & 1) || !a.hin) continue;
       if (!a.enq) {
+        double w0 = trace ? ms() : 0;
         CopyPool::wait(&a.left);
-        HIPCHK(c, hipMemcpyAsync(a.d, (uint8_t*)c->pin + a.off, a.bytes, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->pev[i], c->copy_stream));
+        double w1 = trace ? ms() : 0;
+        RC(xfer(a.d, (uint8_t*)c->pin + a.off, a.bytes, hipMemcpyHostToDevice, c->copy_stream, c->copy_stream2, ev1[i],
+                ev2[i]));
         a.enq = true;
+        if (trace)
+          fprintf(stderr, "[pipe] %7.2f ms H2D of array %d enqueued (%.1f MB, waited %.2f ms for its staging, %.2f ms in the enqueue)\n",
+                  ms(), i, a.bytes / 1e6, w1 - w0, ms() - w1);
       }
-      HIPCHK(c, hipStreamWaitEvent(tgt, c->pev[i], 0));
+      HIPCHK(c, hipStreamWaitEvent(tgt, ev1[i], 0));
+    }
+    return GS_OK;
+  }
+  // the output arrays in `mask` are complete once the work enqueued so far on the current stream is done: their D2H
+  // starts behind it on the copy-out streams, under whatever kernels follow
+  int out_ready(unsigned mask) {
+    if (c->rec) return GS_OK;  // launches are only being recorded: nothing has been computed yet
+    hipStream_t src = c->cur ? c->cur : c->stream;
+    bool first = true;
+    for (int i = 0; i < n; i++) {
+      Arr& a = arr[i];
+      if (!((mask >> i) & 1) || !a.hout || a.enq) continue;
+      if (first) {
+        HIPCHK(c, hipEventRecord(c->pev_ready, src));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_out_stream, c->pev_ready, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_out_stream2, c->pev_ready, 0));
+        first = false;
+      }
+      RC(xfer((uint8_t*)c->pin + a.off, a.d, a.bytes, hipMemcpyDeviceToHost, c->copy_out_stream, c->copy_out_stream2,
+              ev1[i], ev2[i]));
+      a.enq = true;
+      out_order[n_out++] = i;
+      if (trace) fprintf(stderr, "[pipe] %7.2f ms D2H of array %d enqueued (%.1f MB)\n", ms(), i, a.bytes / 1e6);
     }
     return GS_OK;
   }
   // outputs: D2H per array behind the kernels, each copied on to the caller's buffer while the next one is in flight
   int finish() {
     c->pipe = nullptr;
-    for (int i = 0; i < n; i++) {
+    if (trace) fprintf(stderr, "[pipe] %7.2f ms kernels enqueued\n", ms());
+    hipStream_t keep = c->cur;
+    c->cur = nullptr;
+    int rc = out_ready(0xFFFFu);  // whatever has not gone out yet, behind the last kernel
+    c->cur = keep;
+    RC(rc);
+    for (int k = 0; k < n_out; k++) {  // in arrival order: an early array is on its way to the caller while later ones fly
+      const int i = out_order[k];
       Arr& a = arr[i];
-      if (!a.hout) continue;
-      HIPCHK(c, hipMemcpyAsync((uint8_t*)c->pin + a.off, a.d, a.bytes, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipEventRecord(c->pev[i], c->stream));
-    }
-    for (int i = 0; i < n; i++) {
-      Arr& a = arr[i];
-      if (!a.hout) continue;
-      HIPCHK(c, hipEventSynchronize(c->pev[i]));
+      HIPCHK(c, hipEventSynchronize(ev1[i]));
+      if (trace) fprintf(stderr, "[pipe] %7.2f ms array %d arrived\n", ms(), i);
       c->pool->submit(a.hout, (uint8_t*)c->pin + a.off, a.bytes, &a.left);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) CopyPool::wait(&arr[i].left);
+    if (trace) fprintf(stderr, "[pipe] %7.2f ms done\n", ms());
     return GS_OK;
   }
 };
 static inline int need(gs_ctx* c, unsigned mask) { return c->pipe ? c->pipe->need(mask) : GS_OK; }
+static inline int out_ready(gs_ctx* c, unsigned mask) { return c->pipe ? c->pipe->out_ready(mask) : GS_OK; }
 // array slots of the host-pointer entry points
 enum { PI_X = 0, PI_Y, PI_A, PI_B, PI_G, PI_R, PI_S, PI_T, PO_XC, PO_YC, PO_PI, PO_TH };           // prove
 enum { VI_A = 0, VI_B, VI_G, VI_TG, VI_XC, VI_YC, VI_PI, VI_TH, VO_OK };                            // verify
 #define BIT(i) (1u << (i))
+
+// the batch size the lane-shape planners should fill the chip for: the part's own, or (mixed calls, whose parts'
+// launches are merged) the whole call's
+static inline size_t fillN(const gs_ctx* c, size_t N) { return c->fill_n > N ? c->fill_n : N; }
 
 // ---- Miller-lane planning --------------------------------------------------------------------------
 // A Miller lane carries up to MILLER_CH (P, Q) pairs (twin: (Q, P0, P1) triples with two accumulators) and squares its
@@ -494,13 +582,15 @@ static std::vector<double> miller_budgets(const gs_ctx* c, bool twin) {
   return out;
 }
 
-// k_var_multi lanes per launch: their Straus tables live in a per-context workspace of 3.5 .. 28 KB per lane (G2, 8
-// terms, 5-bit windows: 28 KB).  Four rounds of resident waves (simd_slots x 64 lanes each) keep the launch overhead
-// below 1 % and bound the workspace at ~7 GB for the largest lane (2 GB for the 2^16 PPE shapes) whatever the batch.
-static inline size_t var_ws_default(const gs_ctx* c) { return 4 * c->simd_slots * 64; }
+// k_var_multi lanes per launch: their Straus tables (affine table + the Jacobian staging of its build) live in a
+// per-context workspace of 9 .. 70 KB per lane (G2, 8 terms, 5-bit windows: 28 + 42 KB).  Two rounds of resident waves
+// (simd_slots x 64 lanes each) keep the launch overhead below 1 % and bound the workspace at 9.2 GB for the largest
+// lane whatever the batch.
+static inline size_t var_ws_default(const gs_ctx* c) { return 2 * c->simd_slots * 64; }
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
 template <class K, class... Args>
 static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, Args... args) {
+  if (c->rec) return fail(c, GS_ERR_ARG, "internal: this kernel cannot be part of a merged launch");
   if (total == 0) return GS_OK;
   unsigned grid = (unsigned)((total + block - 1) / block);
   hipStream_t st = c->cur ? c->cur : c->stream;
@@ -522,6 +612,126 @@ static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, 
   }
   c->work_hint = 0;
   return GS_OK;
+}
+
+// ---- segmented launches (csrc/gs_kernels.cuh: k_seg) ----------------------------------------------------------------
+// launch_seg<Body>(c, name, lanes, block, args...) runs a kernel BODY over one segment -- or, while a mixed call is
+// recording (c->rec), only notes the launch.  replay() then walks the parts' launch lists in step and merges the launches
+// that run the same body (same instantiation, same block size) into one k_seg launch with a segment per part.
+struct LaunchRec {
+  std::string name;
+  const void* kern = nullptr;  // address of the k_seg instantiation: the identity of the body
+  size_t total = 0;
+  int block = 64;
+  uint64_t work = 0;
+  std::vector<uint8_t> pack;   // the bytes of this launch's Pack<args...>
+  int (*go)(gs_ctx*, const LaunchRec* const*, int) = nullptr;
+};
+struct Recorder {
+  std::vector<std::vector<LaunchRec>> parts;
+  int cur = 0;
+};
+template <class Body, class... A> static int go_seg(gs_ctx* c, const LaunchRec* const* r, int nr) {
+  Segs<A...> S;
+  memset((void*)&S, 0, sizeof S);
+  S.n = nr;
+  size_t lanes = 0, tot = 0;
+  uint64_t work = 0;
+  const int block = r[0]->block;
+  for (int i = 0; i < nr; i++) {
+    S.lo[i] = lanes;
+    memcpy((void*)&S.a[i], r[i]->pack.data(), sizeof(Pack<A...>));
+    lanes += (r[i]->total + block - 1) / block * block;
+    tot += r[i]->total;
+    work += r[i]->work ? r[i]->work : r[i]->total;
+  }
+  if (lanes == 0) return GS_OK;
+  hipStream_t st = c->cur ? c->cur : c->stream;
+  if (c->prof) hipEventRecord(c->ev0, st);
+  hipLaunchKernelGGL((k_seg<Body, A...>), dim3((unsigned)(lanes / block)), dim3(block), 0, st, S);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, GS_ERR_DEVICE, r[0]->name.c_str(), e);
+  if (c->prof) {
+    hipEventRecord(c->ev1, st);
+    hipEventSynchronize(c->ev1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    const std::string& name = r[0]->name;
+    if (!c->prof_map.count(name)) c->prof_order.push_back(name);
+    ProfEntry& p = c->prof_map[name];
+    p.ms += ms;
+    p.n += 1;
+    p.lanes += tot;
+    p.work += work;
+  }
+  return GS_OK;
+}
+template <class Body, class... A, class... U>
+static int launch_seg_typed(gs_ctx* c, const char* name, void (*)(size_t, A...), size_t total, int block, U&&... u) {
+  static_assert(sizeof...(A) == sizeof...(U), "argument count of the kernel body");
+  static_assert(sizeof(Segs<A...>) <= 3800, "the segment table travels as a kernel argument");
+  LaunchRec r;
+  r.name = name;
+  r.kern = (const void*)&k_seg<Body, A...>;
+  r.total = total;
+  r.block = block;
+  r.work = c->work_hint;
+  c->work_hint = 0;
+  Pack<A...> pk{{static_cast<A>(u)}...};
+  r.pack.assign((const uint8_t*)&pk, (const uint8_t*)&pk + sizeof pk);
+  r.go = &go_seg<Body, A...>;
+  if (c->rec) {
+    if (total) c->rec->parts[c->rec->cur].push_back(std::move(r));
+    return GS_OK;
+  }
+  if (total == 0) return GS_OK;
+  const LaunchRec* rp = &r;
+  return r.go(c, &rp, 1);
+}
+template <class Body, class... U> static int launch_seg(gs_ctx* c, const char* name, size_t total, int block, U&&... u) {
+  typedef decltype(&Body::run) Sig;  // void (*)(size_t g, args...): the body's own parameter types
+  return launch_seg_typed<Body>(c, name, (Sig) nullptr, total, block, std::forward<U>(u)...);
+}
+// Launch what the parts of a mixed call recorded.  Each part's list is in dependency order (it is what the part would
+// have enqueued on the stream); launches of different parts are independent.  Lock-step merge: the parts whose NEXT
+// launch runs the same body (same instantiation, same block size) form a group that goes out as one segmented launch.
+// When the heads differ (one part has a kernel the others lack, or another variant of it), a group is taken that no
+// other part could still join later -- its body does not occur further down any non-member's list -- so that the parts
+// fall back into step right after it; only if every head is awaited elsewhere does the first unfinished part lead.
+static int replay(gs_ctx* c, Recorder& R) {
+  const size_t np = R.parts.size();
+  std::vector<size_t> cur(np, 0);
+  auto head = [&](size_t p) -> const LaunchRec* { return cur[p] < R.parts[p].size() ? &R.parts[p][cur[p]] : nullptr; };
+  auto same = [](const LaunchRec* a, const LaunchRec* b) { return a->kern == b->kern && a->block == b->block; };
+  for (;;) {
+    size_t lead = np;
+    for (size_t p = 0; p < np && lead == np; p++) {
+      const LaunchRec* h = head(p);
+      if (!h) continue;
+      bool awaited = false;  // does a part that is NOT at this body now still have it ahead?
+      for (size_t q = 0; q < np && !awaited; q++) {
+        const LaunchRec* hq = head(q);
+        if (q == p || !hq || same(hq, h)) continue;
+        for (size_t k = cur[q] + 1; k < R.parts[q].size() && !awaited; k++) awaited = same(&R.parts[q][k], h);
+      }
+      if (!awaited) lead = p;
+    }
+    if (lead == np)
+      for (size_t p = 0; p < np && lead == np; p++)
+        if (head(p)) lead = p;
+    if (lead == np) return GS_OK;
+    const LaunchRec* L = head(lead);
+    const LaunchRec* grp[MAX_SEG];
+    int ng = 0;
+    for (size_t p = 0; p < np && ng < MAX_SEG; p++) {
+      const LaunchRec* h = head(p);
+      if (h && same(h, L)) {
+        grp[ng++] = h;
+        cur[p]++;
+      }
+    }
+    RC(L->go(c, grp, ng));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -911,7 +1121,7 @@ template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLau
     void* out;
     RC(scratch(c, (r.tag + (level & 1 ? ".fold1" : ".fold0")).c_str(), N * (size_t)next * sizeof(Jac<F>), &out));
     c->work_hint = N * (uint64_t)nslots;
-    RC(launch(c, (std::string("k_slot_fold") + r.tag).c_str(), k_slot_fold<C, F>, N * ft.size(), 64, N * ft.size(),
+    RC(launch_seg<k_slot_fold<C, F>>(c, (std::string("k_slot_fold") + r.tag).c_str(), N * ft.size(), 64, N * ft.size(),
               (int)ft.size(), dft, part, nslots, (Jac<F>*)out, (int)next));
     part = (const Jac<F>*)out;
     nslots = (int)next;
@@ -921,17 +1131,17 @@ template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLau
   c->work_hint = N * (uint64_t)nslots;  // partial sums folded
   // outputs per lane (one inversion each lane): as many as still leave the launch a full round of waves
   int K = 1;
-  while (K < RED_K && K * 2 <= (int)r.nred && (N * ((r.nred + 2 * K - 1) / (2 * K)) + 63) / 64 >= c->simd_slots) K *= 2;
+  while (K < RED_K && K * 2 <= (int)r.nred && (fillN(c, N) * ((r.nred + 2 * K - 1) / (2 * K)) + 63) / 64 >= c->simd_slots) K *= 2;
   if (c->red_k > 0) K = std::min(c->red_k, RED_K);
   size_t lanes = N * ((r.nred + K - 1) / K);
-  return launch(c, r.name.c_str(), k_red<C, F>, lanes, 64, lanes, (int)r.nred, dred, part, nslots, r.outs, K);
+  return launch_seg<k_red<C, F>>(c, r.name.c_str(), lanes, 64, lanes, (int)r.nred, dred, part, nslots, r.outs, K);
 }
 template <class C, class F>
 static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
                     int pool_n, const Aff<F>* tab, const OutTab& outs, hipStream_t vstream = nullptr,
                     hipEvent_t vev0 = nullptr, hipEvent_t vev1 = nullptr, RedLaunch* defer = nullptr) {
   std::string t(tag);
-  share_tables(c, N, sp, std::is_same<F, Fp2<C>>::value);
+  share_tables(c, fillN(c, N), sp, std::is_same<F, Fp2<C>>::value);
   const VarTask* dvar;
   const FixTask* dfix;
   RC(upload(c, (t + ".var").c_str(), sp.var, &dvar));
@@ -950,11 +1160,11 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     for (const FixTask& f : sp.fix) terms += (f.t0 != 0xFF) + (f.t1 != 0xFF);
     c->work_hint = N * terms;
   }
-  RC(launch(c, (std::string("k_fix") + tag).c_str(), k_fix<C, F>, N * sp.fix.size(), 64, N * sp.fix.size(),
+  RC(launch_seg<k_fix<C, F>>(c, (std::string("k_fix") + tag).c_str(), N * sp.fix.size(), 64, N * sp.fix.size(),
             (int)sp.fix.size(), dfix, arrs, pool, pool_n, tab, (Jac<F>*)part, sp.nslots));
   if (fork) c->cur = vstream;
   if (sp.tm <= 1) {
-    RC(launch(c, (std::string("k_var") + tag).c_str(), k_var<C, F>, N * sp.var.size(), 64, N * sp.var.size(),
+    RC(launch_seg<k_var<C, F>>(c, (std::string("k_var") + tag).c_str(), N * sp.var.size(), 64, N * sp.var.size(),
               (int)sp.var.size(), dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
   } else {
     const GrpTask* dgrp;
@@ -966,18 +1176,25 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     const int tmax = sp.tm <= 4 ? 4 : 8;
     const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes : var_ws_default(c));
     void* tabws;
-    RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * sizeof(Aff<F>), &tabws));
+    RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * (sizeof(Aff<F>) + sizeof(Jac<F>)), &tabws));
     // kernel name: k_var_multi<TMAX>[w5][x<outputs per lane>]
     std::string kn = std::string("k_var_multi") + (tmax == 4 ? "4" : "8") + (sp.w == 5 ? "w5" : "") +
                      (sp.mo > 1 ? "x" + std::to_string(sp.mo) : "") + tag;
-    auto kern = tmax == 4 ? (sp.w == 5 ? k_var_multi<C, F, 4, 5> : k_var_multi<C, F, 4, 4>)
-                          : (sp.w == 5 ? k_var_multi<C, F, 8, 5> : k_var_multi<C, F, 8, 4>);
     for (size_t g0 = 0; g0 < tot; g0 += chunk) {
       size_t n = std::min(chunk, tot - g0);
       c->work_hint = (uint64_t)((double)N * sp.var.size() * ((double)n / (double)tot));  // terms
-
-      RC(launch(c, kn.c_str(), kern, n, 64, tot, (int)sp.grp.size(), dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part,
-                sp.nslots, g0, (Aff<F>*)tabws));
+#define GS_VM(TM, WW)                                                                                                \
+  RC((launch_seg<k_var_multi<C, F, TM, WW>>(c, kn.c_str(), n, 64, tot, (int)sp.grp.size(), dgrp, dvar, arrs, pool, pool_n, \
+                                            (Jac<F>*)part, sp.nslots, g0, (Aff<F>*)tabws)))
+      if (tmax == 4 && sp.w == 5)
+        GS_VM(4, 5);
+      else if (tmax == 4)
+        GS_VM(4, 4);
+      else if (sp.w == 5)
+        GS_VM(8, 5);
+      else
+        GS_VM(8, 4);
+#undef GS_VM
     }
   }
   if (fork) {  // join before the reduction
@@ -1129,15 +1346,15 @@ template <class C> struct Impl {
                    (yg ? 0u : BIT(PI_Y) | BIT(PI_B))));
     if (wide_prep(m, n)) {  // large arity: one lane per output scalar
       int W = m * kx + n * ky + ky * kx + m + n + kx * n + ky * m;
-      RC(launch(c, "k_prep_prove.a", k_prep_prove_wide_a<C>, N * (size_t)W, 64, N * (size_t)W, W, m, n, kx, ky,
+      RC(launch_seg<k_prep_prove_wide_a<C>>(c, "k_prep_prove.a", N * (size_t)W, 64, N * (size_t)W, W, m, n, kx, ky,
                 (const S*)G, (const S*)R, (const S*)Sm, (const S*)T, xg ? nullptr : (const S*)X,
                 yg ? nullptr : (const S*)Y, pm, (S*)pool, shared ? 1 : 0));
       size_t tb = N * (size_t)(kx * ky + kx + ky);
-      RC(launch(c, "k_prep_prove.b", k_prep_prove_wide_b<C>, tb, 64, tb, m, n, kx, ky, (const S*)R, (const S*)Sm,
+      RC(launch_seg<k_prep_prove_wide_b<C>>(c, "k_prep_prove.b", tb, 64, tb, m, n, kx, ky, (const S*)R, (const S*)Sm,
                 (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
                 yg ? nullptr : (const S*)B, pm, (S*)pool, shared ? 1 : 0));
     } else {
-      RC(launch(c, "k_prep_prove", k_prep_prove<C>, N, 64, N, m, n, kx, ky, (const S*)G, (const S*)R, (const S*)Sm,
+      RC(launch_seg<k_prep_prove<C>>(c, "k_prep_prove", N, 64, N, m, n, kx, ky, (const S*)G, (const S*)R, (const S*)Sm,
                 (const S*)T, xg ? nullptr : (const S*)X, yg ? nullptr : (const S*)Y, xg ? nullptr : (const S*)A,
                 yg ? nullptr : (const S*)B, pm, (S*)pool, shared ? 1 : 0));
     }
@@ -1149,19 +1366,23 @@ template <class C> struct Impl {
     } guard{c};
     // (measured: +18 % at 2^10, but -4 % at 2^12 where each variable-base kernel already fills the SIMDs, so only
     // while a side's variable-base lanes occupy at most half of them)
-    const bool ov = c->overlap && !c->prof && c->side[0] && N * (size_t)(m + n) * 2 <= 32 * c->simd_slots;
+    const bool ov = c->overlap && !c->prof && !c->rec && c->side[0] && fillN(c, N) * (size_t)(m + n) * 2 <= 32 * c->simd_slots;
     if (ov) {
       hipEventRecord(c->sev[0], c->stream);
       hipStreamWaitEvent(c->side[0], c->sev[0], 0);
     }
     // larger batches: only the two reduction kernels (one inversion chain per lane, a few hundred waves each) run
     // side by side, after both sides' partial sums are complete
-    const bool pair_reds = !ov && c->overlap && !c->prof && c->side[0] && N * (size_t)(m + n + 4) <= 64 * c->simd_slots;
+    // (not for a host-pointer call: there the G1 side's outputs go back across PCIe under the G2 side's kernels)
+    // (round 3: OFF.  A side stream is another hardware queue with its own private-segment reservation; two of them
+    // holding a few hundred MB each is what starved the main queue's big kernels of scratch waves later in the
+    // process -- profiles/r3/scratch_pool.txt.  The 1-2 % it gained at 2^12..2^16 are not worth a 4x cliff.)
+    const bool pair_reds = false;
     RedLaunch red1, red2;
     // G1 side: xcoms (m) + theta (ky).  constants A (len n) multiply S; Phi multiplies X; fixed part T.
-    {
+    auto side_g1 = [&](bool first) -> int {
       SidePlan sp;
-      sp.tm = xg ? pick_tm(c, N, m + n, ky, false, ky) : 1;
+      sp.tm = xg ? pick_tm(c, fillN(c, N), m + n, ky, false, ky) : 1;
       build_side(sp, xcoms != nullptr, m, n, xg, kx, ky, pm.RC, pm.XC, pm.SC, pm.PHI, pm.TC, pm.SIG);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -1181,11 +1402,13 @@ template <class C> struct Impl {
       RC(need(c, BIT(PI_X) | BIT(PI_A)));
       RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs,
                           ov ? c->side[1] : nullptr, c->sev[1], c->sev[2], pair_reds ? &red1 : nullptr)));
-    }
+      if (first) RC(out_ready(c, BIT(PO_XC) | BIT(PO_TH)));
+      return GS_OK;
+    };
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
-    {
+    auto side_g2 = [&](bool first) -> int {
       SidePlan sp;
-      sp.tm = yg ? pick_tm(c, N, m + n, kx, true, kx) : 1;
+      sp.tm = yg ? pick_tm(c, fillN(c, N), m + n, kx, true, kx) : 1;
       build_side(sp, ycoms != nullptr, n, m, yg, ky, kx, pm.SC, pm.YC, pm.RC, pm.PSI, pm.OM, pm.RHO);
       ArrTab arrs;
       memset(&arrs, 0, sizeof arrs);
@@ -1211,6 +1434,17 @@ template <class C> struct Impl {
         c->cur = nullptr;
         hipStreamWaitEvent(c->stream, c->sev[5], 0);
       }
+      if (first) RC(out_ready(c, BIT(PO_YC) | BIT(PO_PI)));
+      return GS_OK;
+    };
+    // A host-pointer call runs the G2 side FIRST: its outputs are twice the G1 side's bytes and cross PCIe under the
+    // G1 side's kernels; what is left after the last kernel is the smaller half.  (Device-pointer calls keep G1, G2.)
+    if (c->pipe && !ov) {
+      RC(side_g2(true));
+      RC(side_g1(false));
+    } else {
+      RC(side_g1(c->pipe != nullptr));
+      RC(side_g2(false));
     }
     if (pair_reds) {
       hipEventRecord(c->sev[0], c->stream);  // every partial sum of both sides is enqueued before this point
@@ -1239,7 +1473,7 @@ template <class C> struct Impl {
     void* pool;
     RC(scratch(c, "commit.pool", count * pm.total * sizeof(S), &pool));
     // reuse k_prep_prove with m = 1 variable per "equation", no Gamma work (n = 0, ky = 0)
-    RC(launch(c, "k_prep_commit", k_prep_prove<C>, count, 64, count, 1, 0, kc, 0, (const S*)nullptr, (const S*)rand,
+    RC(launch_seg<k_prep_prove<C>>(c, "k_prep_commit", count, 64, count, 1, 0, kc, 0, (const S*)nullptr, (const S*)rand,
               (const S*)nullptr, (const S*)nullptr, group ? nullptr : (const S*)vars, (const S*)nullptr,
               (const S*)nullptr, (const S*)nullptr, pm, (S*)pool, 0));
     SidePlan sp;
@@ -1384,9 +1618,9 @@ template <class C> struct Impl {
     RC(need(c, BIT(VI_G) | (xg ? 0u : BIT(VI_A)) | (yg ? 0u : BIT(VI_B)) | (ty == GS_QUAD ? BIT(VI_TG) : 0u)));
     const bool wide = wide_prep(m, n);
     if (wide)
-      RC(launch(c, "k_fr_canonical", k_fr_canonical<C>, N * (size_t)m * n, 64, N * (size_t)m * n, m * n, (const S*)G,
+      RC(launch_seg<k_fr_canonical<C>>(c, "k_fr_canonical", N * (size_t)m * n, 64, N * (size_t)m * n, m * n, (const S*)G,
                 pm.total, (S*)pool + pm.GC));
-    RC(launch(c, "k_prep_verify", k_prep_verify<C>, N, 64, N, m, n, wide ? nullptr : (const S*)G,
+    RC(launch_seg<k_prep_verify<C>>(c, "k_prep_verify", N, 64, N, m, n, wide ? nullptr : (const S*)G,
               xg ? nullptr : (const S*)A, yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, pm,
               (S*)pool));
     // lane shape for this batch size: single or twin accumulators (the twin task list on one lane with two
@@ -1396,7 +1630,8 @@ template <class C> struct Impl {
     {
       // the choice depends on the shape, the batch size and the overrides only: remembered per context
       char key[96];
-      snprintf(key, sizeof key, "%d.%d.%d.%zu.%d.%d.%d", ty, m, n, N, c->miller_twin, c->miller_ch, (int)c->line_tables);
+      const size_t NF = fillN(c, N);
+      snprintf(key, sizeof key, "%d.%d.%d.%zu.%d.%d.%d", ty, m, n, NF, c->miller_twin, c->miller_ch, (int)c->line_tables);
       auto hit = c->miller_choice.find(key);
       if (hit != c->miller_choice.end()) {
         mode = hit->second.first;
@@ -1409,7 +1644,7 @@ template <class C> struct Impl {
           for (double cand : miller_budgets(c, md != 0)) {
             VerifyPlan tmp;
             build_verify_miller(tmp, c->curve, ty, m, n, cand, md != 0, c->line_tables);
-            double cost = miller_cost(c, N, tmp.mt, md != 0, md == 2);
+            double cost = miller_cost(c, NF, tmp.mt, md != 0, md == 2);
             if (md == 2) cost *= 0.97;  // measured: the same triples finish 3-4 % sooner with one accumulator per lane
             if (best < 0 || cost < best) {
               best = cost;
@@ -1424,7 +1659,7 @@ template <class C> struct Impl {
       }
     }
     const bool twin = mode != 0;
-    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, N, m, 2 * n, false, n), c->line_tables);
+    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, fillN(c, N), m, 2 * n, false, n), c->line_tables);
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
@@ -1487,16 +1722,16 @@ template <class C> struct Impl {
       c->work_hint = (uint64_t)((double)N * pairs);
     }
     if (mode == 2)
-      RC(launch(c, "k_miller.pair", k_miller_pair<C, false>, 2 * N * ntask, 64, 2 * N * ntask, ntask, dmt, parr, qarr,
+      RC(launch_seg<k_miller_pair<C, false>>(c, "k_miller.pair", 2 * N * ntask, 64, 2 * N * ntask, ntask, dmt, parr, qarr,
                 (GT*)mpart, (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     else if (mode == 3)
-      RC(launch(c, "k_miller.pairdpp", k_miller_pair<C, true>, 2 * N * ntask, 64, 2 * N * ntask, ntask, dmt, parr, qarr,
+      RC(launch_seg<k_miller_pair<C, true>>(c, "k_miller.pairdpp", 2 * N * ntask, 64, 2 * N * ntask, ntask, dmt, parr, qarr,
                 (GT*)mpart, (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     else if (twin)
-      RC(launch(c, "k_miller.twin", k_miller<C, true>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
+      RC(launch_seg<k_miller<C, true>>(c, "k_miller.twin", N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
                 (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     else
-      RC(launch(c, "k_miller", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
+      RC(launch_seg<k_miller<C, false>>(c, "k_miller", N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 2,
                 (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     *mpart_out = mpart;
     return GS_OK;
@@ -1531,7 +1766,7 @@ template <class C> struct Impl {
         void* folded;
         RC(scratch(c, level & 1 ? "verify.mfold1" : "verify.mfold0", 2 * N * (size_t)nt_out * sizeof(GT), &folded));
         size_t total = N * 4 * (size_t)runs_max;
-        RC(launch(c, "k_cell_fold", k_cell_fold<C>, total, 64, total, runs_max, ntask, cm, (const GT*)mpart, K, nt_out, out,
+        RC(launch_seg<k_cell_fold<C>>(c, "k_cell_fold", total, 64, total, runs_max, ntask, cm, (const GT*)mpart, K, nt_out, out,
                   (GT*)folded));
         mpart = folded;
         ntask = nt_out;
@@ -1542,13 +1777,13 @@ template <class C> struct Impl {
     RC(scratch(c, "verify.cellok", N * 4, &cellok));
     // one lane per final exponentiation once that fills the chip, 3-lane groups (21 per wave) below that
     size_t coop_waves = (N * 4 + 20) / 21;
-    if (c->coop_fe == 2 || (c->coop_fe == 1 && coop_waves <= c->simd_slots))
-      RC(launch(c, "k_final.coop", k_final_coop<C>, coop_waves * 63, 63, N, ntask, cm, (const GT*)mpart,
+    if (c->coop_fe == 2 || (c->coop_fe == 1 && (fillN(c, N) * 4 + 20) / 21 <= c->simd_slots))
+      RC(launch_seg<k_final_coop<C>>(c, "k_final.coop", coop_waves * 63, 63, N, ntask, cm, (const GT*)mpart,
                 ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
     else
-      RC(launch(c, "k_final", k_final<C>, N * 4, 64, N, ntask, cm,
+      RC(launch_seg<k_final<C>>(c, "k_final", N * 4, 64, N, ntask, cm,
                 (const GT*)mpart, ty == GS_PPE ? (const uint8_t*)target : nullptr, (uint8_t*)cellok));
-    RC(launch(c, "k_and4", k_and4, N, 64, N, (const uint8_t*)cellok, ok));
+    RC(launch_seg<k_and4>(c, "k_and4", N, 64, N, (const uint8_t*)cellok, ok));
     return GS_OK;
   }
 
@@ -1596,7 +1831,7 @@ template <class C> struct Impl {
     RC(scratch(c, "rlc.pool", N * pm.total * sizeof(S), &pool));
     const bool wide = wide_prep(m, n);
     if (wide)
-      RC(launch(c, "k_fr_canonical", k_fr_canonical<C>, N * (size_t)m * n, 64, N * (size_t)m * n, m * n, (const S*)G,
+      RC(launch_seg<k_fr_canonical<C>>(c, "k_fr_canonical", N * (size_t)m * n, 64, N * (size_t)m * n, m * n, (const S*)G,
                 pm.total, (S*)pool + pm.GC));
     RC(launch(c, "k_prep_verify_rlc", k_prep_verify_rlc<C>, N, 64, N, m, n, wide ? nullptr : (const S*)G,
               xg ? nullptr : (const S*)A, yg ? nullptr : (const S*)B, ty == GS_QUAD ? (const S*)target : nullptr, rho,
@@ -1749,7 +1984,7 @@ template <class C> struct Impl {
         for (int q = 0; q < t.np; q++) pairs += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix / mc.var : 1.0;
       c->work_hint = (uint64_t)((double)N * pairs);
     }
-    RC(launch(c, "k_miller.rlc", k_miller<C, false>, N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 1,
+    RC(launch_seg<k_miller<C, false>>(c, "k_miller.rlc", N * ntask, 64, N * ntask, ntask, dmt, parr, qarr, (GT*)mpart, 1,
               (const Line<C>*)(c->line_tables ? c->tabs->line_tab.p : nullptr)));
     uint8_t* a = (uint8_t*)acc;
     RC(gt_product(c, N * ntask, (GT*)mpart, (GT*)tmp, a));
@@ -1880,7 +2115,7 @@ static int left_mul_impl(gs_ctx* c, int rows, int k, const void* lhs, const void
   pm.total = rows * k;
   void* pool;
   RC(scratch(c, "lm.pool", (size_t)pm.total * sizeof(S), &pool));
-  RC(launch(c, "k_prep_verify", k_prep_verify<C>, 1, 64, (size_t)1, rows, k, (const S*)dl, (const S*)nullptr,
+  RC(launch_seg<k_prep_verify<C>>(c, "k_prep_verify", 1, 64, (size_t)1, rows, k, (const S*)dl, (const S*)nullptr,
             (const S*)nullptr, (const S*)nullptr, pm, (S*)pool));
   SidePlan sp;
   int slot = 0;
@@ -1924,10 +2159,10 @@ template <class C> static int fr_matmul_impl(gs_ctx* c, int rows, int inner, int
   RC(scratch(c, "frmm.pool", (size_t)pm.total * sizeof(S), &pool));
   if (wide_prep(m, n)) {
     int W = m * kx + n * ky + ky * kx + m + n + kx * n + ky * m;
-    RC(launch(c, "k_prep_prove.a", k_prep_prove_wide_a<C>, (size_t)W, 64, (size_t)W, W, m, n, kx, ky, (const S*)dG,
+    RC(launch_seg<k_prep_prove_wide_a<C>>(c, "k_prep_prove.a", (size_t)W, 64, (size_t)W, W, m, n, kx, ky, (const S*)dG,
               (const S*)dR, (const S*)dR, (const S*)dR, (const S*)nullptr, (const S*)nullptr, pm, (S*)pool, 0));
   } else {
-    RC(launch(c, "k_prep_prove", k_prep_prove<C>, 1, 64, (size_t)1, m, n, kx, ky, (const S*)dG, (const S*)dR,
+    RC(launch_seg<k_prep_prove<C>>(c, "k_prep_prove", 1, 64, (size_t)1, m, n, kx, ky, (const S*)dG, (const S*)dR,
               (const S*)dR, (const S*)dR, (const S*)nullptr, (const S*)nullptr, (const S*)nullptr, (const S*)nullptr, pm,
               (S*)pool, 0));
   }
@@ -2062,17 +2297,16 @@ void gs_ctx_destroy(gs_ctx* c) {
     if (st) hipStreamSynchronize(st);
   for (auto& kv : c->plans)
     if (kv.second.dev.p) hipFree(kv.second.dev.p);
-  for (gs_ctx* k : c->kids) gs_ctx_destroy(k);
-  c->kids.clear();
-  hipSetDevice(c->device);
   delete c->pool;
   if (c->pin) hipHostFree(c->pin);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  for (hipStream_t st : {c->copy_stream2, c->copy_out_stream, c->copy_out_stream2})
+    if (st) hipStreamDestroy(st);
   for (hipEvent_t ev : c->pev)
     if (ev) hipEventDestroy(ev);
-  for (hipEvent_t ev : c->kid_ev)
+  for (hipEvent_t ev : c->pev2)
     if (ev) hipEventDestroy(ev);
+  if (c->pev_ready) hipEventDestroy(c->pev_ready);
   c->tabs.reset();  // the CRS tables go with their last context
   for (hipStream_t st : c->side)
     if (st) hipStreamDestroy(st);
@@ -2095,6 +2329,9 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
     if (value < -1 || value > 3)
       return fail(c, GS_ERR_ARG, "miller_twin: -1 (planned), 0 single, 1 twin, 2 lane pair (LDS), 3 lane pair (DPP)");
     c->miller_twin = value;
+  } else if (k == "mixed_merge") {
+    if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "mixed_merge: -1 (planned), 0 parts one after the other, 1 merged launches");
+    c->mixed_merge = value;
   } else if (k == "miller_ch") {
     if (value < 0 || value > MILLER_CH) return fail(c, GS_ERR_ARG, "miller_ch: 0 (planned) .. capacity of a Miller lane");
     c->miller_ch = value;
@@ -2274,7 +2511,7 @@ struct ProveArgs {
   void *xcoms, *ycoms, *pi, *theta;
   bool shared;  // a Statement's part: ONE copy of X, Y, R, S and of the commitments for all N equations
 };
-static int prove_host_stage(gs_ctx* c, const ProveArgs& a, HostPipe& hp) {
+static int prove_host_stage(gs_ctx* c, const ProveArgs& a, HostPipe& hp, size_t base = 0, bool start = true) {
   size_t fq = sz_fq(c->curve), N = a.N;
   bool xg = x_is_group(a.ty), yg = y_is_group(a.ty);
   int kx = xg ? 2 : 1, ky = yg ? 2 : 1, m = a.m, n = a.n;
@@ -2292,9 +2529,9 @@ static int prove_host_stage(gs_ctx* c, const ProveArgs& a, HostPipe& hp) {
   hp.out(PO_YC, a.ycoms, V * n * 8 * fq);
   hp.out(PO_PI, a.pi, N * kx * 8 * fq);
   hp.out(PO_TH, a.theta, N * ky * 4 * fq);
-  // staging order = the order prove() asks for them (scalars, then the G1 side's arguments, then the G2 side's)
-  static const int order[] = {PI_G, PI_R, PI_S, PI_T, PI_X, PI_A, PI_Y, PI_B};
-  return hp.begin(order, 8);
+  // staging order = the order prove() asks for them (scalars, then the G2 side's arguments, then the G1 side's)
+  static const int order[] = {PI_G, PI_R, PI_S, PI_T, PI_Y, PI_B, PI_X, PI_A};
+  return start ? hp.begin(order, 8, base, base == 0) : (int)GS_OK;
 }
 static int prove_host_run(gs_ctx* c, const ProveArgs& a, HostPipe& hp) {
   return (a.shared ? gs_prove_statement_dev : gs_prove_batch_dev)(c, a.ty, a.N, a.m, a.n, hp.dev(PI_X), hp.dev(PI_Y), hp.dev(PI_A), hp.dev(PI_B), hp.dev(PI_G),
@@ -2334,7 +2571,7 @@ struct VerifyArgs {
   uint8_t* ok;
   bool shared;
 };
-static int verify_host_stage(gs_ctx* c, const VerifyArgs& a, HostPipe& hp) {
+static int verify_host_stage(gs_ctx* c, const VerifyArgs& a, HostPipe& hp, size_t base = 0, bool start = true) {
   size_t fq = sz_fq(c->curve), N = a.N;
   int ty = a.ty, m = a.m, n = a.n;
   bool xg = x_is_group(ty), yg = y_is_group(ty);
@@ -2353,7 +2590,7 @@ static int verify_host_stage(gs_ctx* c, const VerifyArgs& a, HostPipe& hp) {
   // Gamma and the G1-side arguments first (the verifier's Gamma-MSM runs under the upload of the rest)
   static const int order_g[] = {VI_G, VI_A, VI_XC, VI_TG, VI_B, VI_YC, VI_PI, VI_TH};
   static const int order_s[] = {VI_G, VI_A, VI_B, VI_TG, VI_XC, VI_YC, VI_PI, VI_TH};
-  return hp.begin(ty == GS_PPE || ty == GS_MSMEG2 ? order_g : order_s, 8);
+  return start ? hp.begin(ty == GS_PPE || ty == GS_MSMEG2 ? order_g : order_s, 8, base, base == 0) : (int)GS_OK;
 }
 static int verify_host_run(gs_ctx* c, const VerifyArgs& a, HostPipe& hp) {
   return (a.shared ? gs_verify_statement_dev : gs_verify_batch_dev)(c, a.ty, a.N, a.m, a.n, hp.dev(VI_A), hp.dev(VI_B), hp.dev(VI_G), hp.dev(VI_TG),
@@ -2375,196 +2612,163 @@ int gs_verify_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, co
 
 // ---- mixed batches: several sub-batches (any types and shapes) in ONE call ----------------------------------------
 // configs[2] of the baseline is a batch of PPE, MSMEG1 and MSMEG2 equations; the reference's Statement is a list of
-// equations of any type (statement.rs:24-28).  Every sub-batch runs the ordinary engine on a CHILD context -- its own
-// stream, scratch and planner state, the parent's CRS tables -- so the kernels of all sub-batches are in flight together
-// and share the SIMDs: a mixed batch of a few thousand equations fills the chip like a homogeneous one of its total
-// size, where three calls in a row run three under-filled launch chains one after the other.  Ordered on the parent's
-// stream like every other _dev call: the children start behind it and it continues behind them.
-static int kid(gs_ctx* c, int i, gs_ctx** out) {
-  while ((int)c->kids.size() <= i) {
-    gs_ctx* k = nullptr;
-    int rc = gs_ctx_create(c->curve, c->device, &k);
-    if (rc != GS_OK) return fail(c, rc, "child context");
-    if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) {
-      gs_ctx_destroy(k);
-      return fail(c, GS_ERR_DEVICE, "child stream");
-    }
-    k->own_stream = true;
-    c->kids.push_back(k);
+// equations of any type (statement.rs:24-28).  The parts run one after the other on the context's stream.
+// Measured and NOT kept (profiles/r3/mixed_streams.txt): one child context per part (own stream, own scratch) so that
+// the parts' kernels are in flight together.  These kernels hold one 512-register wave per SIMD and a private segment
+// each; dispatches from different queues did not share the chip at all (2^12 mixed: 71.1 ms on three streams, 71.3 ms
+// on one), and the extra queues' scratch reservations slowed LATER large batches on the parent fourfold (2^16 PPE
+// 320 -> 1400 ms).  What does fill the chip for a mixed batch of a few thousand equations is merging the lanes of
+// all parts into single launches (segmented launches, section 4.3 of DESIGN.md).
+// Record every part's launches (nothing is enqueued yet), then replay them merged.  Under the kernel profile
+// (gs_prof_enable) and for a single part the parts simply run one after the other.
+// Merged launches pay off while the parts' own launches leave SIMDs idle; from ~2^15 equations on every part fills the
+// chip by itself and separate launches with per-part lane shapes are as fast (measured: profiles/r3/mixed_merge.txt).
+static bool merge_parts(const gs_ctx* c, size_t total_n) {
+  if (c->mixed_merge >= 0) return c->mixed_merge != 0;
+  return total_n <= 32 * c->simd_slots;  // <= 2^15 equations on a 256-CU device
+}
+extern "C++" {
+template <class FN> static int mixed_run(gs_ctx* c, int nparts, size_t total_n, FN part_fn) {
+  if (nparts <= 1 || c->prof || c->rec || !merge_parts(c, total_n)) {
+    for (int i = 0; i < nparts; i++) RC(part_fn(i));
+    return GS_OK;
   }
-  gs_ctx* k = c->kids[i];
-  k->tabs = c->tabs;
-  k->have_crs = c->have_crs;
-  k->var_tm = c->var_tm, k->red_k = c->red_k, k->var_ws_lanes = c->var_ws_lanes, k->var_mo = c->var_mo, k->var_w = c->var_w;
-  k->miller_ch = c->miller_ch, k->miller_twin = c->miller_twin, k->coop_fe = c->coop_fe, k->line_tables = c->line_tables;
-  k->overlap = c->overlap && k->side[0] != nullptr;
-  *out = k;
-  return GS_OK;
-}
-// stream plumbing around the children of one mixed call
-static int kids_fork(gs_ctx* c, int nk) {
-  for (int e = 0; e < 2; e++)
-    if (!c->kid_ev[e]) HIPCHK(c, hipEventCreateWithFlags(&c->kid_ev[e], hipEventDisableTiming));
-  HIPCHK(c, hipEventRecord(c->kid_ev[0], c->stream));
-  for (int i = 0; i < nk; i++) HIPCHK(c, hipStreamWaitEvent(c->kids[i]->stream, c->kid_ev[0], 0));
-  return GS_OK;
-}
-static int kids_join(gs_ctx* c, int nk) {
-  for (int i = 0; i < nk; i++) {
-    HIPCHK(c, hipEventRecord(c->kid_ev[1], c->kids[i]->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->kid_ev[1], 0));
+  Recorder R;
+  R.parts.resize(nparts);
+  c->rec = &R;
+  c->fill_n = total_n;
+  int rc = GS_OK;
+  for (int i = 0; i < nparts && rc == GS_OK; i++) {
+    R.cur = i;
+    c->scratch_tag = i + 1;
+    rc = part_fn(i);
   }
-  return GS_OK;
+  c->rec = nullptr;
+  c->fill_n = 0;
+  c->scratch_tag = 0;
+  RC(rc);  // (a failed part: nothing was launched)
+  return replay(c, R);
 }
-static int kid_fail(gs_ctx* c, gs_ctx* k, int rc) {
-  c->err = k->err;
-  return rc;
-}
-// under the library's kernel profile (gs_prof_enable) the sub-batches run one after the other on the parent itself:
-// the profile is per context and times each launch on its own
-static bool mixed_inline(const gs_ctx* c, int nparts) { return c->prof || nparts == 1; }
-
+}  // extern "C++"
 int gs_prove_mixed_dev(gs_ctx* c, int nparts, const gs_prove_part* p) {
   RC(check_ctx(c, true));
   if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_prove_mixed: 0..8 parts");
-  if (nparts == 0) return GS_OK;
   RangeGuard rg("gs.prove_mixed");
-  if (mixed_inline(c, nparts)) {
-    for (int i = 0; i < nparts; i++)
-      RC((p[i].shared_vars ? gs_prove_statement_dev : gs_prove_batch_dev)(
-          c, p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R, p[i].S, p[i].T,
-          p[i].xcoms, p[i].ycoms, p[i].pi, p[i].theta));
-    return GS_OK;
-  }
-  gs_ctx* k[GS_MIXED_MAX];
-  for (int i = 0; i < nparts; i++) RC(kid(c, i, &k[i]));
-  RC(kids_fork(c, nparts));
-  int rc = GS_OK;
-  for (int i = 0; i < nparts && rc == GS_OK; i++) {
-    rc = (p[i].shared_vars ? gs_prove_statement_dev : gs_prove_batch_dev)(
-        k[i], p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R, p[i].S, p[i].T,
+  size_t tot = 0;
+  for (int i = 0; i < nparts; i++) tot += p[i].N;
+  return mixed_run(c, nparts, tot, [&](int i) {
+    return (p[i].shared_vars ? gs_prove_statement_dev : gs_prove_batch_dev)(
+        c, p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R, p[i].S, p[i].T,
         p[i].xcoms, p[i].ycoms, p[i].pi, p[i].theta);
-    if (rc != GS_OK) kid_fail(c, k[i], rc);
-  }
-  int jr = kids_join(c, nparts);  // also after a failure: what was enqueued stays ordered before the caller's next work
-  return rc != GS_OK ? rc : jr;
+  });
 }
 int gs_verify_mixed_dev(gs_ctx* c, int nparts, const gs_verify_part* p) {
   RC(check_ctx(c, true));
   if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_verify_mixed: 0..8 parts");
-  if (nparts == 0) return GS_OK;
   RangeGuard rg("gs.verify_mixed");
-  if (mixed_inline(c, nparts)) {
-    for (int i = 0; i < nparts; i++)
-      RC((p[i].shared_vars ? gs_verify_statement_dev : gs_verify_batch_dev)(
-          c, p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].A, p[i].B, p[i].Gamma, p[i].target, p[i].xcoms, p[i].ycoms,
-          p[i].pi, p[i].theta, p[i].ok));
-    return GS_OK;
-  }
-  gs_ctx* k[GS_MIXED_MAX];
-  for (int i = 0; i < nparts; i++) RC(kid(c, i, &k[i]));
-  RC(kids_fork(c, nparts));
-  int rc = GS_OK;
-  for (int i = 0; i < nparts && rc == GS_OK; i++) {
-    rc = (p[i].shared_vars ? gs_verify_statement_dev : gs_verify_batch_dev)(
-        k[i], p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].A, p[i].B, p[i].Gamma, p[i].target, p[i].xcoms, p[i].ycoms,
+  size_t tot = 0;
+  for (int i = 0; i < nparts; i++) tot += p[i].N;
+  return mixed_run(c, nparts, tot, [&](int i) {
+    return (p[i].shared_vars ? gs_verify_statement_dev : gs_verify_batch_dev)(
+        c, p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].A, p[i].B, p[i].Gamma, p[i].target, p[i].xcoms, p[i].ycoms,
         p[i].pi, p[i].theta, p[i].ok);
-    if (rc != GS_OK) kid_fail(c, k[i], rc);
-  }
-  int jr = kids_join(c, nparts);
-  return rc != GS_OK ? rc : jr;
+  });
 }
-// host pointers: every sub-batch is staged first (the memcpy workers of all children run together), then all kernels
-// are enqueued, then the outputs come back
-int gs_prove_mixed(gs_ctx* c, int nparts, const gs_prove_part* p) {
-  RC(check_ctx(c, true));
-  if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_prove_mixed: 0..8 parts");
-  for (int i = 0; i < nparts; i++) {
-    RC(check_shape(c, p[i].equ_type, p[i].m, p[i].n));
-    if (p[i].N && (!p[i].X || !p[i].Y || !p[i].A || !p[i].B || !p[i].Gamma || !p[i].R || !p[i].S || !p[i].T || !p[i].pi ||
-                   !p[i].theta))
-      return fail(c, GS_ERR_ARG, "null pointer");
-  }
-  RangeGuard rg("gs.prove_mixed");
-  std::vector<std::unique_ptr<HostPipe>> hp;
-  std::vector<gs_ctx*> k;
-  std::vector<ProveArgs> a;
-  const bool inl = mixed_inline(c, nparts);
-  for (int i = 0; i < nparts; i++) {
-    if (p[i].N == 0) continue;
-    gs_ctx* kc = c;
-    if (!inl) RC(kid(c, (int)k.size(), &kc));
-    k.push_back(kc);
-    a.push_back(ProveArgs{p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R,
-                          p[i].S, p[i].T, p[i].xcoms, p[i].ycoms, p[i].pi, p[i].theta, p[i].shared_vars != 0});
-  }
-  if (inl) {  // one after the other on the parent (a context has one pipe)
-    for (size_t i = 0; i < a.size(); i++) {
+// host pointers: every part is staged into its own region of the pinned buffer (the memcpy workers start at once), the
+// parts' launches are recorded behind their upload events and replayed merged, then the outputs come back
+extern "C++" {
+template <class ARGS, class STAGE, class RUN>
+static int mixed_host(gs_ctx* c, std::vector<ARGS>& a, size_t total_n, STAGE stage, RUN run) {
+  const int np = (int)a.size();
+  if (np <= 1 || c->prof || !merge_parts(c, total_n)) {
+    for (int i = 0; i < np; i++) {
       HostPipe h(c);
-      RC(prove_host_stage(c, a[i], h));
-      RC(prove_host_run(c, a[i], h));
+      RC(stage(c, a[i], h, (size_t)0, true));
+      RC(run(c, a[i], h));
       RC(h.finish());
     }
     return GS_OK;
   }
-  for (size_t i = 0; i < a.size(); i++) {
-    hp.emplace_back(new HostPipe(k[i]));
-    int rc = prove_host_stage(k[i], a[i], *hp[i]);
-    if (rc != GS_OK) return kid_fail(c, k[i], rc);
+  std::vector<std::unique_ptr<HostPipe>> hp;
+  // 1. how much pinned memory the call needs: declare the arrays on throw-away pipes
+  size_t need_pin = 0;
+  std::vector<size_t> base(np, 0);
+  for (int i = 0; i < np; i++) {
+    hp.emplace_back(new HostPipe(c));
+    base[i] = need_pin;
+    need_pin += stage(c, a[i], *hp[i], (size_t)0, false) == GS_OK ? hp[i]->layout() : 0;
   }
+  hp.clear();
+  c->pipe = nullptr;
+  RC(HostPipe::pin_reserve(c, need_pin));
+  // 2. stage for real, every part at its base
   int rc = GS_OK;
-  for (size_t i = 0; i < a.size() && rc == GS_OK; i++)
-    if ((rc = prove_host_run(k[i], a[i], *hp[i])) != GS_OK) kid_fail(c, k[i], rc);
-  for (size_t i = 0; i < a.size(); i++) {
-    int fr = rc == GS_OK ? hp[i]->finish() : (hipStreamSynchronize(k[i]->stream), GS_OK);
-    if (fr != GS_OK && rc == GS_OK) rc = kid_fail(c, k[i], fr);
+  for (int i = 0; i < np && rc == GS_OK; i++) {
+    hp.emplace_back(new HostPipe(c));
+    c->scratch_tag = i + 1;
+    rc = stage(c, a[i], *hp[i], base[i], true);
   }
+  // 3. record the parts' launches (their need() calls enqueue the uploads and make the stream wait), replay merged
+  Recorder R;
+  R.parts.resize(np);
+  c->rec = &R;
+  c->fill_n = total_n;
+  for (int i = 0; i < np && rc == GS_OK; i++) {
+    R.cur = i;
+    c->scratch_tag = i + 1;
+    c->pipe = hp[i].get();
+    rc = run(c, a[i], *hp[i]);
+  }
+  c->rec = nullptr;
+  c->fill_n = 0;
+  c->scratch_tag = 0;
+  c->pipe = nullptr;
+  if (rc == GS_OK) rc = replay(c, R);
+  // 4. outputs
+  for (int i = 0; i < np; i++) {
+    if (rc == GS_OK) {
+      c->scratch_tag = i + 1;
+      rc = hp[i]->finish();
+    }
+  }
+  c->scratch_tag = 0;
+  if (rc != GS_OK) hipStreamSynchronize(c->stream);
   return rc;
+}
+}  // extern "C++"
+int gs_prove_mixed(gs_ctx* c, int nparts, const gs_prove_part* p) {
+  RC(check_ctx(c, true));
+  if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_prove_mixed: 0..8 parts");
+  std::vector<ProveArgs> a;
+  size_t tot = 0;
+  for (int i = 0; i < nparts; i++) {
+    RC(check_shape(c, p[i].equ_type, p[i].m, p[i].n));
+    if (p[i].N == 0) continue;
+    if (!p[i].X || !p[i].Y || !p[i].A || !p[i].B || !p[i].Gamma || !p[i].R || !p[i].S || !p[i].T || !p[i].pi || !p[i].theta)
+      return fail(c, GS_ERR_ARG, "null pointer");
+    a.push_back(ProveArgs{p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].X, p[i].Y, p[i].A, p[i].B, p[i].Gamma, p[i].R,
+                          p[i].S, p[i].T, p[i].xcoms, p[i].ycoms, p[i].pi, p[i].theta, p[i].shared_vars != 0});
+    tot += p[i].N;
+  }
+  RangeGuard rg("gs.prove_mixed");
+  return mixed_host(c, a, tot, prove_host_stage, prove_host_run);
 }
 int gs_verify_mixed(gs_ctx* c, int nparts, const gs_verify_part* p) {
   RC(check_ctx(c, true));
   if (nparts < 0 || nparts > GS_MIXED_MAX || (nparts && !p)) return fail(c, GS_ERR_ARG, "gs_verify_mixed: 0..8 parts");
+  std::vector<VerifyArgs> a;
+  size_t tot = 0;
   for (int i = 0; i < nparts; i++) {
     RC(check_shape(c, p[i].equ_type, p[i].m, p[i].n));
-    if (p[i].N && (!p[i].A || !p[i].B || !p[i].Gamma || !p[i].target || !p[i].xcoms || !p[i].ycoms || !p[i].pi ||
-                   !p[i].theta || !p[i].ok))
-      return fail(c, GS_ERR_ARG, "null pointer");
-  }
-  RangeGuard rg("gs.verify_mixed");
-  std::vector<std::unique_ptr<HostPipe>> hp;
-  std::vector<gs_ctx*> k;
-  std::vector<VerifyArgs> a;
-  const bool inl = mixed_inline(c, nparts);
-  for (int i = 0; i < nparts; i++) {
     if (p[i].N == 0) continue;
-    gs_ctx* kc = c;
-    if (!inl) RC(kid(c, (int)k.size(), &kc));
-    k.push_back(kc);
+    if (!p[i].A || !p[i].B || !p[i].Gamma || !p[i].target || !p[i].xcoms || !p[i].ycoms || !p[i].pi || !p[i].theta || !p[i].ok)
+      return fail(c, GS_ERR_ARG, "null pointer");
     a.push_back(VerifyArgs{p[i].equ_type, p[i].N, p[i].m, p[i].n, p[i].A, p[i].B, p[i].Gamma, p[i].target, p[i].xcoms,
                            p[i].ycoms, p[i].pi, p[i].theta, p[i].ok, p[i].shared_vars != 0});
+    tot += p[i].N;
   }
-  if (inl) {
-    for (size_t i = 0; i < a.size(); i++) {
-      HostPipe h(c);
-      RC(verify_host_stage(c, a[i], h));
-      RC(verify_host_run(c, a[i], h));
-      RC(h.finish());
-    }
-    return GS_OK;
-  }
-  for (size_t i = 0; i < a.size(); i++) {
-    hp.emplace_back(new HostPipe(k[i]));
-    int rc = verify_host_stage(k[i], a[i], *hp[i]);
-    if (rc != GS_OK) return kid_fail(c, k[i], rc);
-  }
-  int rc = GS_OK;
-  for (size_t i = 0; i < a.size() && rc == GS_OK; i++)
-    if ((rc = verify_host_run(k[i], a[i], *hp[i])) != GS_OK) kid_fail(c, k[i], rc);
-  for (size_t i = 0; i < a.size(); i++) {
-    int fr = rc == GS_OK ? hp[i]->finish() : (hipStreamSynchronize(k[i]->stream), GS_OK);
-    if (fr != GS_OK && rc == GS_OK) rc = kid_fail(c, k[i], fr);
-  }
-  return rc;
+  RangeGuard rg("gs.verify_mixed");
+  return mixed_host(c, a, tot, verify_host_stage, verify_host_run);
 }
 
 // ---- Statement: E equations of one type over the SAME committed variables (statement.rs:24-28,109) -------------

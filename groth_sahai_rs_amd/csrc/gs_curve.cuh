@@ -614,10 +614,14 @@ template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, c
 // registers and become eligible for two waves per SIMD -- and the SAME lanes then take 27 ms instead of 17.7 ms at
 // 2^16 when they are launched as 1024 waves, with k_fix / k_red of the same step slower too; measured on one box,
 // profiles/r2/straus_occupancy.txt.)
+// `tab` = room for the same number of JACOBIAN entries, the staging of the build.  It used to be a local array: 43 KB of
+// private segment per lane for 8 G2 bases with 5-bit windows -- 3 GB of queue scratch for a full chip, which the
+// runtime's scratch pool only grants while no other queue holds any (it then limits the kernel's resident waves: the
+// same step took 1100-1700 ms instead of 320 ms after a small batch had run reductions on a side stream,
+// profiles/r3/scratch_pool.txt).  The kernels pass a second region of the lane's global workspace.
 template <class C, class F, int TMAX, int W>
-GS_HD_NOINLINE void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int nt) {
+GS_HD_NOINLINE void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int nt, Jac<F>* tab) {
   constexpr int NE = 1 << (W - 1);
-  Jac<F> tab[TMAX * NE];
   for (int t = 0; t < nt; t++) smul_build_table_n(tab + t * NE, ps[t], NE);
   table_global_z<C>(at, tab, NE * nt, zback);  // ONE isomorphic curve for all the terms' tables
 }
@@ -682,7 +686,8 @@ GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const 
 template <class C, class F, int TMAX>
 GS_HD void jac_msm_straus_at(Jac<F>& rout, const Aff<F>* ps, const Fr<C>* ks, int nt, Aff<F>* at) {
   F zback;
-  jac_straus_build<C, F, TMAX, 4>(at, zback, ps, nt);
+  Jac<F> tab[TMAX * 8];  // (4-bit windows, small groups: the single-call helper keeps its staging local)
+  jac_straus_build<C, F, TMAX, 4>(at, zback, ps, nt, tab);
   jac_straus_run<C, F, TMAX, 4>(rout, ks, nt, at, zback);
 }
 

@@ -14,6 +14,8 @@
 //   k_final    product of a cell's partial Miller values, final exponentiation,
 //              compare (verifier.rs:50-53)
 #pragma once
+#include <utility>
+
 #include "gs_pairing.cuh"
 #include "gs_coop.cuh"
 #include "gs_wire.cuh"
@@ -71,6 +73,43 @@ struct PoolMap {  // offsets (in scalars) into the per-equation pool
 };
 
 template <class T> __device__ __forceinline__ T ld(const uint8_t* p) { return *reinterpret_cast<const T*>(p); }
+
+// ---- segmented launches ---------------------------------------------------------------------------------------------
+// The kernels of the prove / verify path are written as BODIES: `struct k_xxx { static __device__ void run(size_t g,
+// args...); }`, g = the lane's index within its launch.  One generic __global__ function, k_seg<Body, args...>, runs a
+// body over up to MAX_SEG SEGMENTS: consecutive, block-aligned lane ranges with their own argument packs.  An ordinary
+// launch is one segment.  A mixed batch (gs_prove_mixed / gs_verify_mixed: sub-batches of different equation types and
+// shapes, each with its own task tables and arrays) MERGES the launches of its parts that run the same body into one
+// launch with a segment per part, so that a few thousand equations of three types fill the chip like a homogeneous
+// batch of their total size -- dispatches from several streams do not share these 512-register kernels' SIMDs
+// (profiles/r3/mixed_streams.txt).  The segment of a lane is wave-uniform (segments start at block boundaries, blocks
+// are one wave), so its argument pack is read with scalar loads from the kernel-argument segment exactly as the
+// arguments of an ordinary kernel are.
+constexpr int MAX_SEG = 4;
+template <size_t I, class T> struct PackLeaf {
+  T v;
+};
+template <class Seq, class... A> struct PackImpl;
+template <size_t... I, class... A> struct PackImpl<std::index_sequence<I...>, A...> : PackLeaf<I, A>... {};
+template <class... A> using Pack = PackImpl<std::index_sequence_for<A...>, A...>;
+template <size_t I, class T> __host__ __device__ __forceinline__ const T& pack_get(const PackLeaf<I, T>& l) { return l.v; }
+template <class... A> struct Segs {
+  int n, pad;
+  size_t lo[MAX_SEG];  // first lane of each segment (multiples of the block size, ascending; lo[0] = 0)
+  Pack<A...> a[MAX_SEG];
+};
+template <class Body, class... A, size_t... I>
+__device__ __forceinline__ void seg_call(size_t g, const Pack<A...>& p, std::index_sequence<I...>) {
+  Body::run(g, pack_get<I>(p)...);
+}
+template <class Body, class... A> __global__ void __launch_bounds__(64, GS_WPE) k_seg(Segs<A...> S) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int s = 0;
+  for (int i = 1; i < S.n; i++)
+    if (g >= S.lo[i]) s = i;
+  s = __builtin_amdgcn_readfirstlane(s);
+  seg_call<Body>(g - S.lo[s], S.a[s], std::index_sequence_for<A...>{});
+}
 
 // ---- boundary <-> internal I/O --------------------------------------------------
 // API arrays hold arkworks' saturated Montgomery limbs (BFq); everything the
@@ -200,11 +239,11 @@ __global__ void __launch_bounds__(64, GS_WPE) k_build_tables16(int nb, const Aff
 // Fr preparation for prove (one lane per equation)
 // --------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE)
-    k_prep_prove(size_t N, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R, const Fr<C>* S,
+struct k_prep_prove {
+  static __device__ __forceinline__ void run(size_t e_in, size_t N, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R, const Fr<C>* S,
                  const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm,
                  Fr<C>* pool, int shared_vars) {
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t e = e_in;
   if (e >= N) return;
   typedef Fr<C> S_;
   // shared_vars: a Statement -- every equation of the batch is over the SAME variables (and commit randomness)
@@ -257,16 +296,16 @@ __global__ void __launch_bounds__(64, GS_WPE)
     }
   }
 }
+};
 
 // The same for large arities (m n in the thousands and beyond, benches/bench.rs:451-498 uses 334 x 334): one lane per
 // OUTPUT SCALAR instead of one per equation.  Phase a: conversions and the two matrix products (a lane = one entry
 // of Psi or Phi = one inner product); phase b: the <= 8 scalars per equation that depend on Psi / Phi.
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE)
-    k_prep_prove_wide_a(size_t total, int W, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R,
+struct k_prep_prove_wide_a {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int W, int m, int n, int kx, int ky, const Fr<C>* G, const Fr<C>* R,
                         const Fr<C>* S, const Fr<C>* T, const Fr<C>* xs, const Fr<C>* ys, PoolMap pm, Fr<C>* pool,
                         int shared_vars) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   size_t e = g / W;
   int w = (int)(g % W);
@@ -305,12 +344,12 @@ __global__ void __launch_bounds__(64, GS_WPE)
     P[pm.PHI + l * m + i] = from_mont(phi);
   }
 }
+};
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE)
-    k_prep_prove_wide_b(size_t total, int m, int n, int kx, int ky, const Fr<C>* R, const Fr<C>* S, const Fr<C>* T,
+struct k_prep_prove_wide_b {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int m, int n, int kx, int ky, const Fr<C>* R, const Fr<C>* S, const Fr<C>* T,
                         const Fr<C>* xs, const Fr<C>* ys, const Fr<C>* as, const Fr<C>* bs, PoolMap pm, Fr<C>* pool,
                         int shared_vars) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   const int W = kx * ky + kx + ky;
   size_t e = g / W;
@@ -348,16 +387,17 @@ __global__ void __launch_bounds__(64, GS_WPE)
     P[pm.SIG + l] = from_mont(sig);
   }
 }
+};
 // out[e * out_stride + i] = canonical(in[e * cnt + i]): the Gamma conversion of the verifier, one lane per scalar
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE)
-    k_fr_canonical(size_t total, int cnt, const Fr<C>* in, int out_stride, Fr<C>* out) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+struct k_fr_canonical {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int cnt, const Fr<C>* in, int out_stride, Fr<C>* out) {
   if (g >= total) return;
   size_t e = g / cnt;
   int i = (int)(g % cnt);
   out[e * out_stride + i] = from_mont(in[g]);
 }
+};
 
 // canonical -> Montgomery boundary form (gs_fr_matmul hands the prover's canonical products back as Fr values)
 template <class C>
@@ -369,9 +409,10 @@ __global__ void __launch_bounds__(64, GS_WPE) k_fr_to_mont(size_t total, const F
 
 // Fr preparation for verify: Gamma (and scalar constants / target) -> canonical
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE) k_prep_verify(size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as,
+struct k_prep_verify {
+  static __device__ __forceinline__ void run(size_t e_in, size_t N, int m, int n, const Fr<C>* G, const Fr<C>* as,
                                                     const Fr<C>* bs, const Fr<C>* tq, PoolMap pm, Fr<C>* pool) {
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t e = e_in;
   if (e >= N) return;
   Fr<C>* P = pool + e * pm.total;
   if (G)  // (large arities convert Gamma with k_fr_canonical, one lane per scalar)
@@ -382,6 +423,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_prep_verify(size_t N, int m, int
     for (int i = 0; i < m; i++) P[pm.BC + i] = from_mont(bs[e * m + i]);
   if (tq) P[pm.NT] = from_mont(neg(tq[e]));
 }
+};
 
 template <class C> GS_HD_NOINLINE void f12_pow_u64(Fp12<C>& r, const Fp12<C>& b, uint64_t k) {
   Fp12<C> acc;
@@ -448,9 +490,9 @@ __global__ void __launch_bounds__(64, GS_WPE) k_rlc_tpow(size_t N, const uint8_t
 // linear-combination engine
 // --------------------------------------------------------------------------
 template <class C, class F>
-__global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, const VarTask* tasks, ArrTab arrs,
+struct k_var {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const VarTask* tasks, ArrTab arrs,
                                             const Fr<C>* pool, int pool_n, Jac<F>* part, int nslots) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   size_t e = g / ntask;
   VarTask t = tasks[g % ntask];
@@ -462,19 +504,25 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var(size_t total, int ntask, con
   jac_smul_any<C>(J, P, k);
   part[e * nslots + t.slot] = J;
 }
+};
 
 // joint MSM: one lane = one GrpTask (<= TMAX bases sharing a doubling chain; the lane's table build serves all of the
 // group's outputs, which run one after the other)
 template <class C, class F, int TMAX, int W>
-__global__ void __launch_bounds__(64, GS_WPE) k_var_multi(size_t total, int ngrp, const GrpTask* grps, const VarTask* tasks,
+struct k_var_multi {
+  static __device__ __forceinline__ void run(size_t w_in, size_t total, int ngrp, const GrpTask* grps, const VarTask* tasks,
                                                   ArrTab arrs, const Fr<C>* pool, int pool_n, Jac<F>* part,
                                                   int nslots, size_t g0, Aff<F>* tabws) {
-  size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // lane within this launch = its slot in `tabws`
+  size_t w = w_in;  // lane within this launch = its slot in `tabws`
   size_t g = g0 + w;
   if (g >= total) return;
   size_t e = g / ngrp;
   GrpTask gt = grps[g % ngrp];
-  Aff<F>* at = tabws + w * (size_t)(TMAX << (W - 1));
+  // the lane's workspace: its affine table, then the Jacobian staging of the build (STRAUS_WS_BYTES per lane)
+  constexpr size_t NTAB = (size_t)TMAX << (W - 1);
+  uint8_t* ws = reinterpret_cast<uint8_t*>(tabws) + w * (NTAB * (sizeof(Aff<F>) + sizeof(Jac<F>)));
+  Aff<F>* at = reinterpret_cast<Aff<F>*>(ws);
+  Jac<F>* jt = reinterpret_cast<Jac<F>*>(ws + NTAB * sizeof(Aff<F>));
   F zback;
   {
     Aff<F> P[TMAX];
@@ -483,7 +531,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var_multi(size_t total, int ngrp
       aff_load<C>(P[i], arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
       if (t.neg) P[i].y = neg(P[i].y);
     }
-    jac_straus_build<C, F, TMAX, W>(at, zback, P, (int)gt.nt);
+    jac_straus_build<C, F, TMAX, W>(at, zback, P, (int)gt.nt, jt);
   }
   for (uint32_t o = 0; o < gt.no; o++) {
     Fr<C> k[TMAX];
@@ -493,12 +541,13 @@ __global__ void __launch_bounds__(64, GS_WPE) k_var_multi(size_t total, int ngrp
     part[e * nslots + gt.slot[o]] = J;
   }
 }
+};
 
 template <class C, class F>
-__global__ void __launch_bounds__(64, GS_WPE) k_fix(size_t total, int ntask, const FixTask* tasks, ArrTab arrs,
+struct k_fix {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const FixTask* tasks, ArrTab arrs,
                                             const Fr<C>* pool, int pool_n, const Aff<F>* tab, Jac<F>* part,
                                             int nslots) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   size_t e = g / ntask;
   FixTask t = tasks[g % ntask];
@@ -525,14 +574,15 @@ __global__ void __launch_bounds__(64, GS_WPE) k_fix(size_t total, int ntask, con
   }
   part[e * nslots + t.slot] = acc;
 }
+};
 
 // One lane = up to RED_K consecutive outputs (two points each) and ONE inversion for all of them (Montgomery's trick
 // over their Z coordinates): the inversion is most of this kernel (496 of ~530 Fq multiplications per output in G1).
 constexpr int RED_K = 4;
 template <class C, class F>
-__global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, const RedTask* tasks, const Jac<F>* part,
+struct k_red {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const RedTask* tasks, const Jac<F>* part,
                                             int nslots, OutTab outs, int K) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   const int nl = (ntask + K - 1) / K;  // lanes per equation
   size_t e = g / nl;
@@ -564,6 +614,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_red(size_t total, int ntask, con
     aff_store<C>(o, a);
   }
 }
+};
 
 // Large arities (benches/bench.rs:451-498, m = n = 334): an output is the sum of hundreds of partial slots.  k_red
 // folds its slots serially in ONE lane, so the host first folds runs of K slots in parallel (one lane per run), and
@@ -572,9 +623,9 @@ struct FoldTask {
   uint32_t lo, hi, dst, pad;  // dst slot (in the output array) <- sum of input slots [lo, hi)
 };
 template <class C, class F>
-__global__ void __launch_bounds__(64, GS_WPE) k_slot_fold(size_t total, int ntask, const FoldTask* tasks, const Jac<F>* in,
+struct k_slot_fold {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const FoldTask* tasks, const Jac<F>* in,
                                                           int ns_in, Jac<F>* out, int ns_out) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   size_t e = g / ntask;
   FoldTask t = tasks[g % ntask];
@@ -583,6 +634,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_slot_fold(size_t total, int ntas
   for (uint32_t i = t.lo + 1; i < t.hi; i++) jac_add(s, s, P[i]);
   out[e * ns_out + t.dst] = s;
 }
+};
 
 // --------------------------------------------------------------------------
 // pairing side
@@ -599,9 +651,9 @@ template <class C> __global__ void __launch_bounds__(64, GS_WPE) k_line_tables(c
 // Lanes are TASK-MAJOR: lane g works on task g / N of equation g % N, so a wave holds 64 equations of one task and its
 // lanes agree on the number of pairs and on which of them read line tables (`ltab`, pairs with Q array 2 = CRS).
 template <class C, bool TWIN>
-__global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
+struct k_miller {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
                                                ArrTab qarr, Fp12<C>* out, int ostride, const Line<C>* ltab) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   const size_t N = total / ntask;
   const size_t ti = g / N, e = g % N;
@@ -647,6 +699,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller(size_t total, int ntask, 
     out[(size_t)ostride * go] = f;  // the task's own cell (slot 0 of 2), or densely packed (batched verifier)
   }
 }
+};
 
 // ---- pair-cooperative twin (multi_miller_pair): two lanes per (equation, task), one accumulator each ----------------
 // Exchange policies: how a lane hands its tangent / chord line (6 L dwords) to its partner lane ^ 1.
@@ -697,10 +750,10 @@ template <class C> struct PairDpp {
 // 32 equations of one task.  Same task tables and the same output layout as the twin kernel (out[2 go + a]); the
 // stepping triples of a task come first in its list (chunk_tasks), the table-reading ones after them.
 template <class C, bool DPP>
-__global__ void __launch_bounds__(64, GS_WPE) k_miller_pair(size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
+struct k_miller_pair {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const MillerTask* tasks, ArrTab parr,
                                                     ArrTab qarr, Fp12<C>* out, const Line<C>* ltab) {
   __shared__ int4 xslots[DPP ? 1 : (6 * C::L / 4) * 64];
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;  // total is even: a pair leaves together
   const int a = (int)(g & 1);
   const size_t gp = g >> 1, N = total / (2 * (size_t)ntask);
@@ -746,6 +799,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_miller_pair(size_t total, int nt
   }
   out[2 * go + a] = f;
 }
+};
 
 // Cell c = 2a + b: product of its Miller partials (CellMap), final exponentiation,
 // compare with 1 or the PPE target (verifier.rs:50-53) -> cellok[e*4+c].
@@ -759,10 +813,10 @@ template <class C> GS_HD_NOINLINE void cell_product(Fp12<C>& f, const Fp12<C>* m
 // its run; repeated by the host until k_final's own serial product is short (segmented K-ary tree in GT).
 // Output layout = cell_product's: out[2 * (e * nt_out + cm_out.lo[c] + run) + 0].
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE) k_cell_fold(size_t total, int runs_max, int ntask_in, CellMap cm_in,
+struct k_cell_fold {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int runs_max, int ntask_in, CellMap cm_in,
                                                           const Fp12<C>* in, int K, int nt_out, CellMap cm_out,
                                                           Fp12<C>* out) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   int run = (int)(g % runs_max);
   int c = (int)((g / runs_max) & 3);
@@ -773,11 +827,12 @@ __global__ void __launch_bounds__(64, GS_WPE) k_cell_fold(size_t total, int runs
   for (int i = lo + 1; i < hi; i++) f12_mul(f, f, in[2 * (e * ntask_in + i) + a]);
   out[2 * (e * nt_out + cm_out.lo[c] + run)] = f;
 }
+};
 
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart,
+struct k_final {
+  static __device__ __forceinline__ void run(size_t g, size_t N, int ntask, CellMap cm, const Fp12<C>* mpart,
                                               const uint8_t* target, uint8_t* cellok) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * 4) return;
   size_t e = g >> 2;
   int c = (int)(g & 3);
@@ -795,15 +850,17 @@ __global__ void __launch_bounds__(64, GS_WPE) k_final(size_t N, int ntask, CellM
   }
   cellok[g] = ok ? 1 : 0;
 }
+};
 
 // The same with a 3-lane group per cell (gs_coop.cuh) for batches that cannot fill the chip with one lane per
 // final exponentiation.  blockDim.x == 63: one wave = 21 groups; idle groups of the last wave shadow the last cell so
 // that every lane reaches the shuffles.
 template <class C>
-__global__ void __launch_bounds__(64, GS_WPE) k_final_coop(size_t N, int ntask, CellMap cm, const Fp12<C>* mpart,
+struct k_final_coop {
+  static __device__ __forceinline__ void run(size_t gt, size_t N, int ntask, CellMap cm, const Fp12<C>* mpart,
                                                    const uint8_t* target, uint8_t* cellok) {
-  int lane = (int)threadIdx.x, j = lane % 3;
-  size_t g = (size_t)blockIdx.x * 21 + lane / 3;
+  int lane = (int)(gt % 63), j = lane % 3;  // 63-thread blocks: gt % 63 is the thread within its block (= wave)
+  size_t g = (gt / 63) * 21 + lane / 3;
   bool live = g < N * 4;
   if (!live) g = N * 4 - 1;
   size_t e = g >> 2;
@@ -824,13 +881,16 @@ __global__ void __launch_bounds__(64, GS_WPE) k_final_coop(size_t N, int ntask, 
   }
   if (live && j == 0) cellok[g] = ok ? 1 : 0;
 }
+};
 
-__global__ void k_and4(size_t N, const uint8_t* cellok, uint8_t* ok) {
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+struct k_and4 {
+  static __device__ __forceinline__ void run(size_t e_in, size_t N, const uint8_t* cellok, uint8_t* ok) {
+  size_t e = e_in;
   if (e >= N) return;
   const uint8_t* c = cellok + e * 4;
   ok[e] = (c[0] & c[1] & c[2] & c[3]) ? 1 : 0;
 }
+};
 
 // E::multi_pairing per row: k pairs -> Miller product -> final exponentiation
 template <class C>

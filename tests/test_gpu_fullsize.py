@@ -24,7 +24,8 @@ def spread(N, k=16):
 
 
 # (k_var_multi*: the planner picks the group size together with the window width and the outputs per table build)
-LARGE = ["k_miller.twin", "k_final", "k_var_multi*.g1", "k_var_multi*.g2"]
+# (k_miller.pair*: two lanes per (equation, task) with one accumulator each -- what the planner picks at these sizes)
+LARGE = ["k_miller.pair*", "k_final", "k_var_multi*.g1", "k_var_multi*.g2"]
 
 
 def test_config2_mixed_2p16_bls12_381():

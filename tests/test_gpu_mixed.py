@@ -1,9 +1,10 @@
 """Several sub-batches in ONE call (gs_prove_mixed / gs_verify_mixed, include/gs_amd.h).
 
   * configs[2] of the baseline: a batch that mixes PPE, MSMEG1 and MSMEG2 equations (here also of different shapes)
-    proved and verified in one call, sub-batches in flight together on child contexts, gives byte-for-byte what one
-    gs_prove_batch / gs_verify_batch call per sub-batch gives, through host pointers and through device pointers, and
-    with the library's kernel profile on (the inline path);
+    proved and verified in one call -- the parts' launches recorded and MERGED into segmented launches (k_seg: one
+    launch per kernel body with a segment per part) -- gives byte-for-byte what one gs_prove_batch / gs_verify_batch
+    call per sub-batch gives, through host pointers and through device pointers, and with the library's kernel
+    profile on (parts one after the other: the kernel names of a merged launch must show in the profile-free run);
   * a mixed-type STATEMENT (statement.rs:24-28,109: equations of any type over ONE list of variables): the variables are
     committed once per group, 70 equations of the four types (two waves of PPEs) get their proofs in one call, and EVERY
     equation's pi / theta and the shared commitments equal the C oracle's commit_and_prove with the same X, Y, R, S and
@@ -43,7 +44,7 @@ def test_mixed_batch_equals_one_call_per_sub_batch():
         want.append({k: host(getattr(wl, k)) for k in OUT_P})
         hostin.append({k: host(getattr(wl, k)) for k in IN_P + ("target",)})
     parts = [dict(ty=ty, N=N, m=m, n=n, **{k: h[k] for k in IN_P}) for (ty, N, m, n), h in zip(shapes, hostin)]
-    for prof in (False, True):  # children in flight together / one after the other under the kernel profile
+    for prof in (False, True):  # merged segmented launches / one part after the other under the kernel profile
         eng.prof_enable(prof)
         got = eng.prove_mixed(parts)
         for g, w in zip(got, want):
@@ -68,7 +69,7 @@ def test_mixed_batch_equals_one_call_per_sub_batch():
     eng.prove_mixed_dev(dparts)
     eng.verify_mixed_dev([dict(ty=wl.ty, N=wl.N, m=wl.m, n=wl.n, A=wl.A, B=wl.B, Gamma=wl.Gamma, target=wl.target,
                                xcoms=wl.xcoms, ycoms=wl.ycoms, pi=wl.pi, theta=wl.theta, ok=wl.ok) for wl in wls])
-    eng.sync()  # the parent's stream continues behind its children
+    eng.sync()
     torch.cuda.synchronize()
     for wl, w in zip(wls, want):
         for k in OUT_P:

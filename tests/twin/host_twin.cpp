@@ -265,14 +265,16 @@ template <class C> struct Twin {
         int n = nt & 15, w = (nt >> 8) & 15, mo = nt >> 12;
         if (op == 17) {
           static Aff<F1> at[8 * 16];
+          static Jac<F1> jt1[8 * 16];
           F1 zb;
-          if (w == 5) jac_straus_build<C, F1, 8, 5>(at, zb, P, n); else jac_straus_build<C, F1, 8, 4>(at, zb, P, n);
+          if (w == 5) jac_straus_build<C, F1, 8, 5>(at, zb, P, n, jt1); else jac_straus_build<C, F1, 8, 4>(at, zb, P, n, jt1);
           for (int o = 0; o < mo; o++)
             if (w == 5) jac_straus_run<C, F1, 8, 5>(J1, k, n, at, zb); else jac_straus_run<C, F1, 8, 4>(J1, k, n, at, zb);
         } else {
           static Aff<F2> at[8 * 16];
+          static Jac<F2> jt2[8 * 16];
           F2 zb;
-          if (w == 5) jac_straus_build<C, F2, 8, 5>(at, zb, Q, n); else jac_straus_build<C, F2, 8, 4>(at, zb, Q, n);
+          if (w == 5) jac_straus_build<C, F2, 8, 5>(at, zb, Q, n, jt2); else jac_straus_build<C, F2, 8, 4>(at, zb, Q, n, jt2);
           for (int o = 0; o < mo; o++)
             if (w == 5) jac_straus_run<C, F2, 8, 5>(J2, k, n, at, zb); else jac_straus_run<C, F2, 8, 4>(J2, k, n, at, zb);
         }

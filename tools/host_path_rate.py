@@ -1,20 +1,55 @@
-"""PCIe-inclusive rate of the host-pointer entry points (gs_prove_batch / gs_verify_batch):
-inputs start in host memory, results end in host memory.  Reported in DESIGN.md only;
-bench.py's `value` is the device-resident rate."""
-import sys, time, os
+"""PCIe-inclusive rate of the host-pointer entry points (gs_prove_batch / gs_verify_batch): inputs start in pageable host
+memory, results end in host memory, next to the device-resident rate of the same batch on the same box.
+    python tools/host_path_rate.py [log2 N] [steps]          (GS_COPY_THREADS=k python ... for the worker sweep)"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
 import groth_sahai_rs_amd as gs
 from groth_sahai_rs_amd.workload import Workload
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+N = 1 << log2n
 eng = gs.Engine(0, 0)
-wl = Workload(eng, N=N)
+wl = Workload(eng, N=N, corrupt_every=0)
 h = lambda t: t.cpu().numpy()
 X, Y, A, B, G, R, S, T, tgt = map(h, (wl.X, wl.Y, wl.A, wl.B, wl.Gamma, wl.R, wl.S, wl.T, wl.target))
-for it in range(3):
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = eng.prove_batch(0, N, 4, 4, X, Y, A, B, G, R, S, T)
-    ok = eng.verify_batch(0, N, 4, 4, A, B, G, tgt, out["xcoms"], out["ycoms"], out["pi"], out["theta"])
-    dt = time.perf_counter() - t0
-    assert ok.all()
-    print("host path: %d units in %.1f ms = %.0f proofs+verifies/s (H2D + D2H + staging allocations included)" % (N, dt * 1e3, N / dt))
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, r
+
+
+def dev_prove():
+    wl.prove()
+    eng.sync()
+
+
+def dev_verify():
+    wl.verify()
+    eng.sync()
+
+
+tp_d, _ = timed(dev_prove, steps)
+tv_d, _ = timed(dev_verify, steps)
+tp_h, out = timed(lambda: eng.prove_batch(0, N, 4, 4, X, Y, A, B, G, R, S, T), steps)
+tv_h, ok = timed(lambda: eng.verify_batch(0, N, 4, 4, A, B, G, tgt, out["xcoms"], out["ycoms"], out["pi"], out["theta"]), steps)
+assert ok.all() and (out["pi"] == h(wl.pi)).all()
+inb = sum(a.nbytes for a in (X, Y, A, B, G, R, S, T))
+outb = sum(v.nbytes for v in out.values())
+vin = A.nbytes + B.nbytes + G.nbytes + tgt.nbytes + outb
+print("2^%d PPE, GS_COPY_THREADS=%s: prove dev %.1f host %.1f ms (+%.1f: %.0f MB in, %.0f MB out); verify dev %.1f host %.1f ms "
+      "(+%.1f: %.0f MB in); host/dev rate ratio %.3f; host %.0f /s" % (
+          log2n, os.environ.get("GS_COPY_THREADS", "4"), tp_d, tp_h, tp_h - tp_d, inb / 1e6, outb / 1e6, tv_d, tv_h,
+          tv_h - tv_d, vin / 1e6, (tp_d + tv_d) / (tp_h + tv_h), N / (tp_h + tv_h) * 1e3))
