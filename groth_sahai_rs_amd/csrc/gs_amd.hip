@@ -117,6 +117,7 @@ struct gs_ctx {
   // mixed calls: launches are recorded per part and merged (launch_seg / replay); scratch buffers get a per-part tag;
   // the lane-shape planners see the batch size the merged launches will have
   struct Recorder* rec = nullptr;
+  int var_tab = -1;      // verifier's Gamma^T c on shared per-base window tables: -1 planned (large arities), 0, 1
   int mixed_merge = -1;  // -1 planned (merge while the parts cannot fill the chip on their own), 0 never, 1 always
   int scratch_tag = 0;
   size_t fill_n = 0;
@@ -832,6 +833,9 @@ struct SidePlan {
   std::vector<FixTask> fix;
   std::vector<RedTask> red;
   int nslots = 0;
+  int ncom = 0;  // the first `ncom` reductions (the commitments) only sum fixed-base partial slots
+  int tab_bases = 0;  // > 0: every variable-base term is over array 0, which holds this many bases per equation, and
+                      // the side runs on shared per-base window tables (k_tab_build + k_var_tab) instead of Straus lanes
 };
 
 static FixTask mkfix(int s0, int t0, int s1, int t1, int a_arr, int a_idx, int slot, int a_neg = 0) {
@@ -961,6 +965,7 @@ static void share_tables(const gs_ctx* c, size_t N, SidePlan& sp, bool g2) {
   sp.shared_done = true;
   sp.mo = 1;
   sp.w = 4;
+  if (sp.tab_bases > 0) return;  // the lanes read the bases' shared tables: nothing to build per lane, one output each
   if (sp.tm <= 1 || sp.grp.empty()) return;
   // families of groups over the same bases, in plan order: hash of (nt, (index, array, sign) of every base), with
   // the bases compared on a hash match (large arities have ~10^5 groups: no strings, no ordered map)
@@ -1060,6 +1065,7 @@ static void build_side(SidePlan& sp, bool want_coms, int nv, int nc, bool group,
       }
       sp.red.push_back(mkred(s_begin, s_begin + 1, s_begin + 1, s_begin + 2, 0, i));
     }
+    sp.ncom = nv;
   }
   for (int l = 0; l < npf; l++) {
     int b0 = slot;
@@ -1139,7 +1145,10 @@ template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLau
 template <class C, class F>
 static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const ArrTab& arrs, const Fr<C>* pool,
                     int pool_n, const Aff<F>* tab, const OutTab& outs, hipStream_t vstream = nullptr,
-                    hipEvent_t vev0 = nullptr, hipEvent_t vev1 = nullptr, RedLaunch* defer = nullptr) {
+                    hipEvent_t vev0 = nullptr, hipEvent_t vev1 = nullptr, RedLaunch* defer = nullptr,
+                    const unsigned* pipe_masks = nullptr) {
+  // pipe_masks (host-pointer calls): {inputs the fixed-base kernel reads, inputs the variable-base kernel reads,
+  // outputs complete after the commitments' reduction, outputs complete after the side's last reduction}
   std::string t(tag);
   share_tables(c, fillN(c, N), sp, std::is_same<F, Fp2<C>>::value);
   const VarTask* dvar;
@@ -1155,6 +1164,7 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     hipEventRecord(vev0, base);
     hipStreamWaitEvent(vstream, vev0, 0);
   }
+  if (pipe_masks) RC(need(c, pipe_masks[0]));
   {
     uint64_t terms = 0;  // fixed-base scalars per equation
     for (const FixTask& f : sp.fix) terms += (f.t0 != 0xFF) + (f.t1 != 0xFF);
@@ -1162,8 +1172,44 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
   }
   RC(launch_seg<k_fix<C, F>>(c, (std::string("k_fix") + tag).c_str(), N * sp.fix.size(), 64, N * sp.fix.size(),
             (int)sp.fix.size(), dfix, arrs, pool, pool_n, tab, (Jac<F>*)part, sp.nslots));
+  // host-pointer calls: the commitments depend on the fixed-base kernel alone -- reduce them now and send them back
+  // across PCIe under the variable-base kernel
+  // (from 2^14 equations on: below that the extra launch and events cost more than the copy they hide)
+  const bool early = c->pipe && pipe_masks && !c->rec && !fork && !defer && sp.ncom > 0 && sp.ncom < (int)sp.red.size() &&
+                     N >= 16 * c->simd_slots;
+  if (early) {
+    RedLaunch rc0;
+    rc0.name = std::string("k_red") + tag;
+    rc0.tag = t + ".coms";
+    rc0.hred.assign(sp.red.begin(), sp.red.begin() + sp.ncom);
+    rc0.part = part;
+    rc0.nred = (size_t)sp.ncom;
+    rc0.nslots = sp.nslots;
+    rc0.outs = outs;
+    RC((run_red<C, F>(c, N, rc0)));
+    RC(out_ready(c, pipe_masks[2]));
+  }
   if (fork) c->cur = vstream;
-  if (sp.tm <= 1) {
+  // (the variable-base kernel reads the variables too, and on a forked stream nothing has waited for them yet)
+  if (pipe_masks) RC(need(c, pipe_masks[0] | pipe_masks[1]));
+  if (sp.tab_bases > 0) {
+    // shared per-base window tables (8-bit signed windows: 128 affine multiples per base), then Straus-shaped lanes of
+    // up to 8 terms that only read them
+    constexpr int TW = 8, TNE = 1 << (TW - 1);
+    const size_t nbt = N * (size_t)sp.tab_bases;
+    void *tabs, *stage;
+    RC(scratch(c, (t + ".tab8").c_str(), nbt * TNE * sizeof(Aff<F>), &tabs));
+    RC(scratch(c, (t + ".tab8j").c_str(), nbt * TNE * sizeof(Jac<F>), &stage));
+    c->work_hint = nbt;
+    RC((launch_seg<k_tab_build<C, F, TW>>(c, (std::string("k_tab_build") + tag).c_str(), nbt, 64, nbt, sp.tab_bases, arrs, 0,
+                                          (Jac<F>*)stage, (Aff<F>*)tabs)));
+    const GrpTask* dgrp;
+    RC(upload(c, (t + ".grp").c_str(), sp.grp, &dgrp));
+    const size_t tot = N * sp.grp.size();
+    c->work_hint = N * sp.var.size();  // terms
+    RC((launch_seg<k_var_tab<C, F, 8, TW>>(c, (std::string("k_var_tab8") + tag).c_str(), tot, 64, tot, (int)sp.grp.size(), dgrp,
+                                           dvar, pool, pool_n, (Jac<F>*)part, sp.nslots, (const Aff<F>*)tabs, sp.tab_bases)));
+  } else if (sp.tm <= 1) {
     RC(launch_seg<k_var<C, F>>(c, (std::string("k_var") + tag).c_str(), N * sp.var.size(), 64, N * sp.var.size(),
               (int)sp.var.size(), dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
   } else {
@@ -1205,16 +1251,21 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
   RedLaunch r;
   r.name = std::string("k_red") + tag;
   r.tag = t;
-  r.hred = sp.red;
+  if (early)
+    r.hred.assign(sp.red.begin() + sp.ncom, sp.red.end());
+  else
+    r.hred = sp.red;
   r.part = part;
-  r.nred = sp.red.size();
+  r.nred = r.hred.size();
   r.nslots = sp.nslots;
   r.outs = outs;
   if (defer) {
     *defer = r;
     return GS_OK;
   }
-  return run_red<C, F>(c, N, r);
+  RC((run_red<C, F>(c, N, r)));
+  if (pipe_masks) RC(out_ready(c, pipe_masks[2] | pipe_masks[3]));
+  return GS_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1399,10 +1450,11 @@ template <class C> struct Impl {
       outs.base[1] = (uint8_t*)theta;
       outs.stride[1] = (uint32_t)(ky * Z::COM1);
       RangeGuard rg("gs.prove.g1");
-      RC(need(c, BIT(PI_X) | BIT(PI_A)));
+      // (the fixed-base kernel reads X as the commitments' affine addend; the constants A only feed the variable-base one)
+      const unsigned masks[4] = {BIT(PI_X), BIT(PI_A), BIT(PO_XC), BIT(PO_TH)};
       RC((run_side<C, F1>(c, ".g1", N, sp, arrs, (const S*)pool, pm.total, (const A1*)c->tabs->tab16_g1.p, outs,
-                          ov ? c->side[1] : nullptr, c->sev[1], c->sev[2], pair_reds ? &red1 : nullptr)));
-      if (first) RC(out_ready(c, BIT(PO_XC) | BIT(PO_TH)));
+                          ov ? c->side[1] : nullptr, c->sev[1], c->sev[2], pair_reds ? &red1 : nullptr, masks)));
+      (void)first;
       return GS_OK;
     };
     // G2 side: ycoms (n) + pi (kx).  constants B (len m) multiply R; Psi multiplies Y; fixed part Omega.
@@ -1426,24 +1478,25 @@ template <class C> struct Impl {
       outs.stride[1] = (uint32_t)(kx * Z::COM2);
       if (ov) c->cur = c->side[0];  // the whole G2 side runs beside the G1 side
       RangeGuard rg("gs.prove.g2");
-      RC(need(c, BIT(PI_Y) | BIT(PI_B)));
+      const unsigned masks[4] = {BIT(PI_Y), BIT(PI_B), BIT(PO_YC), BIT(PO_PI)};
       RC((run_side<C, F2>(c, ".g2", N, sp, arrs, (const S*)pool, pm.total, (const A2*)c->tabs->tab16_g2.p, outs,
-                          ov ? c->side[2] : nullptr, c->sev[3], c->sev[4], pair_reds ? &red2 : nullptr)));
+                          ov ? c->side[2] : nullptr, c->sev[3], c->sev[4], pair_reds ? &red2 : nullptr, masks)));
       if (ov) {
         hipEventRecord(c->sev[5], c->side[0]);
         c->cur = nullptr;
         hipStreamWaitEvent(c->stream, c->sev[5], 0);
       }
-      if (first) RC(out_ready(c, BIT(PO_YC) | BIT(PO_PI)));
+      (void)first;
       return GS_OK;
     };
-    // A host-pointer call runs the G2 side FIRST: its outputs are twice the G1 side's bytes and cross PCIe under the
-    // G1 side's kernels; what is left after the last kernel is the smaller half.  (Device-pointer calls keep G1, G2.)
-    if (c->pipe && !ov) {
+    // A host-pointer call runs the G2 side FIRST: every output but the last proof element crosses PCIe under later
+    // kernels (the commitments of a side under its variable-base kernel, the first side's proof element under the second
+    // side), and the one that is left after the last kernel is then theta (1/8 of the output bytes) rather than pi.
+    if (c->pipe && !ov && N >= 16 * c->simd_slots) {
       RC(side_g2(true));
       RC(side_g1(false));
     } else {
-      RC(side_g1(c->pipe != nullptr));
+      RC(side_g1(true));
       RC(side_g2(false));
     }
     if (pair_reds) {
@@ -1523,6 +1576,10 @@ template <class C> struct Impl {
     // engine arrays: 0 = xcoms as 2m G1 points, 1 = A (group), 2 = target (MSMEG1)
     SidePlan& sp = vp.g1;
     sp.tm = tm;
+    if (tm < 0) {  // shared per-base tables: groups of 8 terms, array 0 = the 2 m components of the X commitments
+      sp.tm = 8;
+      sp.tab_bases = 2 * m;
+    }
     int slot = 0;
     for (int j = 0; j < n; j++) {
       int b[2], e[2];
@@ -1659,7 +1716,11 @@ template <class C> struct Impl {
       }
     }
     const bool twin = mode != 0;
-    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, pick_tm(c, fillN(c, N), m, 2 * n, false, n), c->line_tables);
+    // the Gamma^T c lanes: Straus groups with their own tables, or (large arities: every base serves 2 n outputs)
+    // lanes over shared per-base window tables -- measured in profiles/r3/large_arity_334.json
+    const bool tab8 = c->var_tab == 1 || (c->var_tab < 0 && wide_prep(m, n) && n >= 32);
+    build_verify(vp, c->curve, ty, m, n, pm, budget, twin, tab8 ? -1 : pick_tm(c, fillN(c, N), m, 2 * n, false, n),
+                 c->line_tables);
     // G1-side points
     void* pa;
     RC(scratch(c, "verify.pa", N * vp.npa * Z::COM1, &pa));
@@ -2329,6 +2390,9 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
     if (value < -1 || value > 3)
       return fail(c, GS_ERR_ARG, "miller_twin: -1 (planned), 0 single, 1 twin, 2 lane pair (LDS), 3 lane pair (DPP)");
     c->miller_twin = value;
+  } else if (k == "var_tab") {
+    if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "var_tab: -1 (planned), 0 Straus lanes, 1 shared per-base window tables");
+    c->var_tab = value;
   } else if (k == "mixed_merge") {
     if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "mixed_merge: -1 (planned), 0 parts one after the other, 1 merged launches");
     c->mixed_merge = value;
@@ -2530,7 +2594,7 @@ static int prove_host_stage(gs_ctx* c, const ProveArgs& a, HostPipe& hp, size_t 
   hp.out(PO_PI, a.pi, N * kx * 8 * fq);
   hp.out(PO_TH, a.theta, N * ky * 4 * fq);
   // staging order = the order prove() asks for them (scalars, then the G2 side's arguments, then the G1 side's)
-  static const int order[] = {PI_G, PI_R, PI_S, PI_T, PI_Y, PI_B, PI_X, PI_A};
+  static const int order[] = {PI_G, PI_R, PI_S, PI_T, PI_Y, PI_B, PI_X, PI_A};  // (Y before B: the fixed-base kernel reads Y)
   return start ? hp.begin(order, 8, base, base == 0) : (int)GS_OK;
 }
 static int prove_host_run(gs_ctx* c, const ProveArgs& a, HostPipe& hp) {

@@ -338,6 +338,29 @@ template <class F> GS_HD_NOINLINE void smul_build_table_n(Jac<F>* tab, const Aff
   }
 }
 
+// out[i] = (i + 1) P in AFFINE form, i < ne: Jacobian chain into `stage`, one inversion for all entries (Montgomery's
+// trick).  P of prime order and ne < r: no multiple is the identity unless P is.
+template <class F> GS_HD_NOINLINE void smul_affine_table(Aff<F>* out, Jac<F>* stage, const Aff<F>& p, int ne) {
+  if (aff_is_inf(p)) {
+    for (int i = 0; i < ne; i++) out[i].x = zero_of<F>(), out[i].y = zero_of<F>();
+    return;
+  }
+  smul_build_table_n(stage, p, ne);
+  F acc = one_of<F>();
+  for (int i = 0; i < ne; i++) {
+    out[i].x = acc;  // prefix product of the Z before entry i
+    acc = mul(acc, stage[i].z);
+  }
+  F iv = inv(acc);
+  for (int i = ne - 1; i >= 0; i--) {
+    F zi = mul(out[i].x, iv);  // 1 / Z_i
+    iv = mul(iv, stage[i].z);
+    F z2 = sqr(zi);
+    out[i].x = mul(stage[i].x, z2);
+    out[i].y = mul(stage[i].y, mul(z2, zi));
+  }
+}
+
 // ---- lattice decomposition (BN curves: no eigenvalue of size sqrt(r) / r^(1/4) exists, so the sub-scalars come from
 // Babai rounding against a reduced basis B of {v : sum v_j eig^j = 0 mod r}; gen_params.py derives and checks B and
 // G_i = floor(2^256 |(B^-1)_0i|)).  c_i = floor(k G_i / 2^256) (sign GS_i), k_j = [j = 0] k - sum_i c_i B_ij.
@@ -625,8 +648,12 @@ GS_HD_NOINLINE void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int
   for (int t = 0; t < nt; t++) smul_build_table_n(tab + t * NE, ps[t], NE);
   table_global_z<C>(at, tab, NE * nt, zback);  // ONE isomorphic curve for all the terms' tables
 }
+// `tabs` (optional): per-term table pointers instead of the lane's own contiguous `at` -- window tables of the BASES
+// that many lanes share (k_var_tab: one table per (equation, base), true affine entries, zback = 1); `negm` bit t
+// then stands for "-P_t".
 template <class C, class F, int TMAX, int W>
-GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F>* at, const F& zback) {
+GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F>* at, const F& zback,
+                                   const Aff<F>* const* tabs = nullptr, uint32_t negm = 0) {
   constexpr int NE = 1 << (W - 1);
   Jac<F> r;  // the running sum stays a local (registers): a reference parameter is memory at every step
   if constexpr (C::HAS_ENDO) {
@@ -650,9 +677,9 @@ GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const 
         for (int s = 0; s < E::NS; s++) {
           int a = dg[t][s * ND + i];
           if (a == 0) continue;
-          Aff<F> e = at[t * NE + (a < 0 ? -a : a) - 1];
+          Aff<F> e = tabs ? tabs[t][(a < 0 ? -a : a) - 1] : at[t * NE + (a < 0 ? -a : a) - 1];
           endo_apply<C>(e, s);
-          if ((a < 0) != (sg[t][s] != 0)) e.y = neg(e.y);
+          if (((a < 0) != (sg[t][s] != 0)) != (((negm >> t) & 1) != 0)) e.y = neg(e.y);
           jac_madd(r, r, e);
         }
     }

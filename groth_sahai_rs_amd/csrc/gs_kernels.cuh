@@ -543,6 +543,52 @@ struct k_var_multi {
 }
 };
 
+// ---- large arities: window tables of the BASES, shared by every output that uses them --------------------------------
+// The verifier's Gamma^T c is 2 n outputs over the SAME 2 m commitment components (benches/bench.rs:451-498: m = n = 334).
+// A Straus lane builds its own tables (8 bases x 16 entries, shared by at most 4 outputs); with hundreds of outputs per
+// base it pays to build ONE wide table per (equation, base) -- 2^(W-1) = 128 true-affine multiples for 8-bit signed
+// windows, one inversion per base -- and let every output's lanes read them: 2 x 17 look-ups and mixed additions per
+// term instead of 2 x 27, one shared doubling chain of 128 instead of 130 doublings, no per-lane build at all.
+template <class C, class F, int W>
+struct k_tab_build {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int nb, ArrTab arrs, int arr, Jac<F>* stage, Aff<F>* tabs) {
+  if (g >= total) return;
+  constexpr int NE = 1 << (W - 1);
+  size_t e = g / nb;
+  int b = (int)(g % nb);
+  Aff<F> P;
+  aff_load<C>(P, arrs.base[arr] + e * arrs.stride[arr] + (size_t)b * AFFB(C, F));
+  smul_affine_table(tabs + g * NE, stage + g * NE, P, NE);
+}
+};
+// one lane = one GrpTask as in k_var_multi (<= TMAX terms sharing the doubling chain, `no` outputs one after the other);
+// base t of the group is entry tasks[..].p_idx of array 0, its table tabs[(e * nb + p_idx) * NE ..]
+template <class C, class F, int TMAX, int W>
+struct k_var_tab {
+  static __device__ __forceinline__ void run(size_t g, size_t total, int ngrp, const GrpTask* grps, const VarTask* tasks,
+                                              const Fr<C>* pool, int pool_n, Jac<F>* part, int nslots, const Aff<F>* tabs,
+                                              int nb) {
+  if (g >= total) return;
+  constexpr int NE = 1 << (W - 1);
+  size_t e = g / ngrp;
+  GrpTask gt = grps[g % ngrp];
+  for (uint32_t o = 0; o < gt.no; o++) {
+    Fr<C> k[TMAX];
+    const Aff<F>* tp[TMAX];
+    uint32_t negm = 0;
+    for (uint32_t i = 0; i < gt.nt; i++) {
+      VarTask t = tasks[gt.first[o] + i];
+      k[i] = pool[e * pool_n + t.s_idx];
+      tp[i] = tabs + (e * (size_t)nb + t.p_idx) * NE;
+      if (t.neg) negm |= 1u << i;
+    }
+    Jac<F> J;
+    jac_straus_run<C, F, TMAX, W>(J, k, (int)gt.nt, (const Aff<F>*)nullptr, one_of<F>(), tp, negm);
+    part[e * nslots + gt.slot[o]] = J;
+  }
+}
+};
+
 template <class C, class F>
 struct k_fix {
   static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const FixTask* tasks, ArrTab arrs,

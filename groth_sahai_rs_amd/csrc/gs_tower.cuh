@@ -319,6 +319,32 @@ GS_ML void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const 
   // every coefficient is a sum of three Fp2 products = one dot3 kernel (14 L^2 multiply-adds, output N): 84 L^2 against
   // the 78 L^2 of the Karatsuba form below, and none of its ~3 500 additions, carry rounds and copies around them.
   const Fp2<C> a0 = f.c0.c0, a1 = f.c0.c1, a2 = f.c0.c2, b0 = f.c1.c0, b1 = f.c1.c1, b2 = f.c1.c2;
+#if defined(GS_LINE_ORDER)
+  // Round-3 experiment: the calls that take xi-multiples first and next to each other (every xi-multiple is dead after
+  // the third call), so that the live set -- six old coefficients, the line, the outputs so far, the multiplier's own
+  // registers -- stays below 512 dwords instead of ~550.
+  Fp2<C> n00, n01, n02, n10, n11, n12;
+  {
+    const Fp2<C> xa2 = norm(mul_xi(a2));
+    {
+      const Fp2<C> xb1 = norm(mul_xi(b1));
+      n00 = dot3(a0, l0, xa2, l1, xb1, l4);
+    }
+    const Fp2<C> xb2 = norm(mul_xi(b2));
+    n10 = dot3(b0, l0, xb2, l1, xa2, l4);
+    n01 = dot3(a1, l0, a0, l1, xb2, l4);
+  }
+  n02 = dot3(a2, l0, a1, l1, b0, l4);
+  n11 = dot3(b1, l0, b0, l1, a0, l4);
+  n12 = dot3(b2, l0, b1, l1, a1, l4);
+  f.c0.c0 = n00;
+  f.c0.c1 = n01;
+  f.c0.c2 = n02;
+  f.c1.c0 = n10;
+  f.c1.c1 = n11;
+  f.c1.c2 = n12;
+  return;
+#endif
   const Fp2<C> xa2 = norm(mul_xi(a2)), xb1 = norm(mul_xi(b1)), xb2 = norm(mul_xi(b2));
   // (the line coefficients keep their operand slots through all six calls: only the f-side registers change)
   f.c0.c0 = dot3(a0, l0, xa2, l1, xb1, l4);

@@ -83,6 +83,8 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "coop_fe"       0 one lane per final exponentiation | 1 planned | 2 always the 3-lane cooperative form
  *   "line_tables"   1 CRS G2 arguments read precomputed Miller lines | 0 they are stepped like any other point
  *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream
+ *   "var_tab"      -1 planned | 0 the verifier's Gamma^T c on Straus lanes with their own tables | 1 on window tables of
+ *                   the commitment components shared by all outputs (8-bit windows; what large arities use)
  *   "mixed_merge"  -1 planned | 0 the parts of a mixed call run one after the other | 1 their launches are merged
  * The same knobs are read ONCE at gs_ctx_create from the environment for experiments without recompiling the caller:
  * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_VAR_MO, GS_VAR_W, GS_RED_K, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP (same values).

@@ -38,6 +38,10 @@ SHAPES = {
                                        line_tables=0, overlap=0),
     "pair3_straus2_lane_overlap": dict(red_k=1, miller_twin=2, miller_ch=3, var_tm=2, var_mo=1, var_w=4, coop_fe=0,
                                        line_tables=1, overlap=1),
+    # the verifier's Gamma^T c on window tables of the commitment components shared by all outputs (what large arities
+    # use; forced here at 4 x 4): k_tab_build + k_var_tab8
+    "pair12_tab8_lane": dict(red_k=2, miller_twin=3, miller_ch=12, var_tm=8, var_mo=2, var_w=5, coop_fe=0, line_tables=1,
+                             overlap=0, var_tab=1),
 }
 MILLER_KERNEL = {0: "k_miller", 1: "k_miller.twin", 2: "k_miller.pair", 3: "k_miller.pairdpp"}
 
@@ -62,7 +66,10 @@ def expected_kernels(ty, m, n, o):
         ex.append(var_name(m + n, ".g1"))
     if yg:
         ex.append(var_name(m + n, ".g2"))
-    ex.append(var_name(m, ".vg1"))
+    if o.get("var_tab") == 1:
+        ex += ["k_tab_build.vg1", "k_var_tab8.vg1"]
+    else:
+        ex.append(var_name(m, ".vg1"))
     return ex
 
 
@@ -98,7 +105,7 @@ def test_option_values_are_validated():
     eng = gs.Engine(0, 0)
     try:
         for key, bad in (("no_such_option", 1), ("miller_ch", 13), ("miller_twin", 4), ("var_tm", 9), ("var_mo", 3),
-                         ("var_w", 6), ("red_k", 3), ("var_ws_lanes", 100), ("coop_fe", 3)):
+                         ("var_w", 6), ("red_k", 3), ("var_ws_lanes", 100), ("coop_fe", 3), ("var_tab", 2), ("mixed_merge", 2)):
             with pytest.raises(gs.GsError):
                 eng.set_option(key, bad)
         for key, good in (("miller_ch", 12), ("var_mo", 4), ("var_w", 5), ("red_k", 4), ("var_ws_lanes", 128),

@@ -14,8 +14,11 @@ from groth_sahai_rs_amd.workload import Workload
 
 m = n = int(sys.argv[1]) if len(sys.argv) > 1 else 334
 out = {}
-for N in (1, 16):
+# A/B of the verifier's Gamma^T c: Straus lanes with their own tables (var_tab = 0) against window
+# tables of the 2 m commitment components shared by all 2 n outputs (var_tab = 1: k_tab_build + k_var_tab8)
+for N, tab in ((1, 0), (1, 1), (16, 0), (16, 1)):
     eng = gs.Engine(0, 0)
+    eng.set_option("var_tab", tab)
     wl = Workload(eng, ty=0, N=N, m=m, n=n, seed=334 + N, corrupt_every=0)
     for _ in range(2):
         wl.prove()
@@ -39,6 +42,8 @@ for N in (1, 16):
     eng.sync()
     prof = {p[0]: round(p[1], 3) for p in eng.prof_get()}
     eng.prof_enable(False)
-    out["N=%d" % N] = {"prove_ms": tp * 1e3, "verify_ms": tv * 1e3, "kernels_ms": prof}
+    out["N=%d %s" % (N, "shared base tables (k_var_tab8)" if tab else "Straus lanes")] = {
+        "prove_ms": tp * 1e3, "verify_ms": tv * 1e3, "gamma_msm_ms": sum(v for k, v in prof.items() if ".vg1" in k),
+        "kernels_ms": prof}
     eng.close()
 print(json.dumps({"shape": "PPE %dx%d BLS12-381" % (m, n), **out}))
