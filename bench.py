@@ -443,6 +443,8 @@ class Bench:
             "frac": achieved / 8000.0,
             "traffic": traffic,
             "traffic_source": src,
+            # HBM bytes the dominant kernel moved per launch / the algorithmic bytes of the units it processed
+            "traffic_ratio": (traffic / (N * bpu)) if traffic else None,
             "avg_kernel_ms": ms / max(launches, 1),
             "bytes_per_unit": bpu,
             "kernel_share_of_step": ms / tot,

@@ -319,10 +319,11 @@ GS_ML void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const 
   // every coefficient is a sum of three Fp2 products = one dot3 kernel (14 L^2 multiply-adds, output N): 84 L^2 against
   // the 78 L^2 of the Karatsuba form below, and none of its ~3 500 additions, carry rounds and copies around them.
   const Fp2<C> a0 = f.c0.c0, a1 = f.c0.c1, a2 = f.c0.c2, b0 = f.c1.c0, b1 = f.c1.c1, b2 = f.c1.c2;
-#if defined(GS_LINE_ORDER)
-  // Round-3 experiment: the calls that take xi-multiples first and next to each other (every xi-multiple is dead after
-  // the third call), so that the live set -- six old coefficients, the line, the outputs so far, the multiplier's own
-  // registers -- stays below 512 dwords instead of ~550.
+  // Call order (round 3): the calls that take xi-multiples come first and next to each other, every xi-multiple is
+  // dead after the third call, the results are written back at the end.  Live set: six old coefficients + the line +
+  // the outputs so far + two xi-multiples + the multiplier's own registers = ~440 dwords; with all three xi-multiples
+  // computed up front and the outputs stored as they came it was ~550 > 512, and every line product moved ~410 dwords
+  // through the private segment (now ~310): k_miller.pairdpp 167.1 -> 158.5 ms at 2^16, same box.
   Fp2<C> n00, n01, n02, n10, n11, n12;
   {
     const Fp2<C> xa2 = norm(mul_xi(a2));
@@ -345,16 +346,6 @@ GS_ML void f12_mul_by_014(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l1, const 
   f.c1.c2 = n12;
   return;
 #endif
-  const Fp2<C> xa2 = norm(mul_xi(a2)), xb1 = norm(mul_xi(b1)), xb2 = norm(mul_xi(b2));
-  // (the line coefficients keep their operand slots through all six calls: only the f-side registers change)
-  f.c0.c0 = dot3(a0, l0, xa2, l1, xb1, l4);
-  f.c0.c1 = dot3(a1, l0, a0, l1, xb2, l4);
-  f.c0.c2 = dot3(a2, l0, a1, l1, b0, l4);
-  f.c1.c0 = dot3(b0, l0, xb2, l1, xa2, l4);
-  f.c1.c1 = dot3(b1, l0, b0, l1, a0, l4);
-  f.c1.c2 = dot3(b2, l0, b1, l1, a1, l4);
-  return;
-#endif
   Fp6<C> aa, bb, s, t;
   f6_mul_by_01(aa, f.c0, l0, l1);
   f6_mul_by_1(bb, f.c1, l4);
@@ -372,13 +363,29 @@ GS_ML void f12_mul_by_034(Fp12<C>& f, const Fp2<C>& l0, const Fp2<C>& l3, const 
 #if !defined(GS_NO_SPARSE_DOT3)
   //   c0' = A l0 + v B (l3 + l4 v),  c1' = A (l3 + l4 v) + B l0
   const Fp2<C> a0 = f.c0.c0, a1 = f.c0.c1, a2 = f.c0.c2, b0 = f.c1.c0, b1 = f.c1.c1, b2 = f.c1.c2;
-  const Fp2<C> xa2 = norm(mul_xi(a2)), xb1 = norm(mul_xi(b1)), xb2 = norm(mul_xi(b2));
-  f.c0.c0 = dot3(a0, l0, xb2, l3, xb1, l4);
-  f.c0.c1 = dot3(a1, l0, b0, l3, xb2, l4);
-  f.c0.c2 = dot3(a2, l0, b1, l3, b0, l4);
-  f.c1.c0 = dot3(b0, l0, a0, l3, xa2, l4);
-  f.c1.c1 = dot3(b1, l0, a1, l3, a0, l4);
-  f.c1.c2 = dot3(b2, l0, a2, l3, a1, l4);
+  // (same call order as f12_mul_by_014: xi-multiples first and short-lived, results written back at the end)
+  Fp2<C> n00, n01, n02, n10, n11, n12;
+  {
+    const Fp2<C> xb2 = norm(mul_xi(b2));
+    {
+      const Fp2<C> xb1 = norm(mul_xi(b1));
+      n00 = dot3(a0, l0, xb2, l3, xb1, l4);
+    }
+    n01 = dot3(a1, l0, b0, l3, xb2, l4);
+  }
+  {
+    const Fp2<C> xa2 = norm(mul_xi(a2));
+    n10 = dot3(b0, l0, a0, l3, xa2, l4);
+  }
+  n02 = dot3(a2, l0, b1, l3, b0, l4);
+  n11 = dot3(b1, l0, a1, l3, a0, l4);
+  n12 = dot3(b2, l0, a2, l3, a1, l4);
+  f.c0.c0 = n00;
+  f.c0.c1 = n01;
+  f.c0.c2 = n02;
+  f.c1.c0 = n10;
+  f.c1.c1 = n11;
+  f.c1.c2 = n12;
   return;
 #endif
   Fp6<C> aa, bb, s, t;

@@ -5,7 +5,7 @@
 #    separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) of the 2^16 and 2^12 PPE configurations reduced by
 #    tools/summarize_pmc.py, the large-arity latencies.  Copy what is to be judged into profiles/<tag>/.
 set -eo pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -22,5 +22,6 @@ for args in "--log2n 15" "--log2n 17" "--log2n 14" "--log2n 16 --mode rlc" "--lo
   echo "done $name"
 done
 python3 tools/large_arity_rate.py > $O/large_arity_334.json
-python3 tools/host_path_rate.py > $O/host_path_rate.txt
+for n in 16 14 12; do python3 tools/host_path_rate.py $n 4 2>/dev/null | tail -1; done > $O/host_path_rate.txt
+python3 tools/mixed_rate.py 10 12 14 16 2>/dev/null > $O/mixed_merge.txt
 ls -la $O
