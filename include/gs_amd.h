@@ -101,7 +101,16 @@ int gs_sizes(int curve_id, size_t out[6]);
  * builds the fixed-base window tables (16-bit windows: 1.8 GB of device memory) and the Miller
  * line tables of its G2 elements on the device.  The tables are immutable and SHARED: every context of the process
  * that installs the same CRS bytes on the same device uses one copy (reference-counted; freed with the last context),
- * so a pool of worker contexts costs 1.8 GB per device, not per worker. */
+ * so a pool of worker contexts costs 1.8 GB per device, not per worker.
+ * What IS per context (grow-only, sized by the largest batch the context has seen; freed by gs_ctx_destroy):
+ *   - engine scratch: scalar pool, Jacobian partial slots, Miller partials: ~1 GB at 2^16 PPEs of 4 + 4 variables;
+ *   - the Straus lanes' workspaces (affine tables + the Jacobian staging of their build): 9 .. 70 KB per lane, at most
+ *     2 x (SIMDs of the device) x 64 lanes per side ("var_ws_lanes" lowers that): <= 9.2 GB for the largest lane
+ *     shape (G2, 8 terms, 5-bit windows), ~6 GB in total for the 2^16 PPE shapes;
+ *   - host-pointer entry points only: a pinned host buffer and device staging of the call's input + output bytes each
+ *     (0.45 GB for a 2^16 PPE prove);
+ *   - large arities only: the shared per-base window tables, N x 2 m x 128 entries (14 KB per base in G1).
+ * A pool of W worker contexts on one GPU therefore costs 1.8 GB + W x (the above for the workers' batch size). */
 int gs_set_crs(gs_ctx* ctx, const void* crs_host);
 
 /* CRS of the reference's shape (src/generator.rs:81-118, binding key :48-60) from caller-drawn values:

@@ -330,6 +330,168 @@ using MSMEG1 = Equation<G1Affine, Fr, G1Affine, EquType::MultiScalarG1>;
 using MSMEG2 = Equation<Fr, G2Affine, G2Affine, EquType::MultiScalarG2>;
 using QuadEqu = Equation<Fr, Fr, Fr, EquType::Quadratic>;
 
+// ---- `pub type Statement = Vec<dyn Equ>` (statement.rs:24-28,109): "a list of equations ... defined with respect to
+// the list of variables that span across ALL equations" -- unusable in the reference (a Vec of an unsized type), made
+// usable here.  The variables are four lists -- G1 variables xg, G2 variables yg, scalar variables xs (committed into
+// B1) and ys (into B2); a PPE is over (xg, yg), an MSMEG1 over (xg, ys), an MSMEG2 over (xs, yg), a QuadEqu over
+// (xs, ys) (statement.rs:117-192) -- each committed ONCE, and every equation of every type gets its own EquProof
+// against those commitments in ONE call of the engine (gs_prove_mixed / gs_verify_mixed with shared_vars parts: the
+// launches of the parts are merged on the device).  Draw order: the commit randomness of xg, yg, xs, ys, then T of
+// equation 0, 1, ...  Exactly what batch_commit_* followed by Provable::prove per equation with shared Commit1 /
+// Commit2 does in the reference.
+struct StatementVars {
+  std::vector<G1Affine> xg;
+  std::vector<G2Affine> yg;
+  std::vector<Fr> xs, ys;
+};
+struct StatementProof {
+  Commit1 com_xg, com_xs;
+  Commit2 com_yg, com_ys;
+  std::vector<EquProof> equ_proofs;  // one per equation, in the statement's order
+};
+class Statement {
+  struct Item {  // one equation, type-erased to bytes
+    EquType ty;
+    size_t na, nb, rows, cols;  // a_consts, b_consts, Gamma rows / columns (checked against the groups' sizes)
+    Bytes A, B, G, target;
+    bool ragged;
+  };
+  std::vector<Item> items;
+  static bool xgroup(EquType t) { return t == EquType::PairingProduct || t == EquType::MultiScalarG1; }
+  static bool ygroup(EquType t) { return t == EquType::PairingProduct || t == EquType::MultiScalarG2; }
+  struct Part {
+    EquType ty;
+    std::vector<size_t> idx;
+    Bytes A, B, G, T, target, pi, theta;
+    std::vector<uint8_t> ok;
+  };
+  std::vector<Part> parts() const {
+    std::vector<Part> ps;
+    for (size_t i = 0; i < items.size(); i++) {
+      size_t k = 0;
+      while (k < ps.size() && ps[k].ty != items[i].ty) k++;
+      if (k == ps.size()) ps.push_back(Part{items[i].ty, {}, {}, {}, {}, {}, {}, {}, {}, {}});
+      ps[k].idx.push_back(i);
+    }
+    return ps;
+  }
+  void check(const Item& it, size_t m, size_t n) const {
+    assert_eq(it.na, n, "a_consts.len() == yvars.len()");
+    assert_eq(it.nb, m, "b_consts.len() == xvars.len()");
+    assert_eq(it.rows, m, "gamma.len() == xvars.len()");
+    if (it.ragged || it.cols != n) throw Panic("assertion failed: gamma[i].len() == yvars.len()");
+  }
+
+ public:
+  size_t size() const { return items.size(); }
+  template <class A1, class A2, class AT, EquType TYPE> void push(const Equation<A1, A2, AT, TYPE>& e) {
+    Item it{TYPE, e.a_consts.size(), e.b_consts.size(), e.gamma.size(), e.gamma.empty() ? 0 : e.gamma[0].size(),
+            cat(e.a_consts), cat(e.b_consts), cat(e.gamma), e.target.v, false};
+    for (const auto& row : e.gamma) it.ragged = it.ragged || row.size() != it.cols;
+    items.push_back(std::move(it));
+  }
+
+  template <class Rng> StatementProof commit_and_prove(const StatementVars& v, const CRS& crs, Rng& rng) const {
+    StatementProof out;
+    out.com_xg = batch_commit_G1(v.xg, crs, rng);
+    out.com_yg = batch_commit_G2(v.yg, crs, rng);
+    out.com_xs = batch_commit_scalar_to_B1(v.xs, crs, rng);
+    out.com_ys = batch_commit_scalar_to_B2(v.ys, crs, rng);
+    std::vector<Matrix<Fr>> Ts;
+    for (const Item& it : items) Ts.push_back(detail::draw(rng, ygroup(it.ty) ? 2 : 1, xgroup(it.ty) ? 2 : 1));
+    const Ctx& cx = *crs.ctx;
+    std::vector<Part> ps = parts();
+    if (ps.size() > GS_MIXED_MAX) throw Panic("more equation types than a mixed call takes");
+    std::vector<gs_prove_part> cp(ps.size());
+    Bytes Xg = cat(v.xg), Yg = cat(v.yg), Xs = cat(v.xs), Ys = cat(v.ys);
+    Bytes Rg = cat(out.com_xg.rand), Sg = cat(out.com_yg.rand), Rs = cat(out.com_xs.rand), Ss = cat(out.com_ys.rand);
+    for (size_t k = 0; k < ps.size(); k++) {
+      Part& p = ps[k];
+      const bool xg = xgroup(p.ty), yg = ygroup(p.ty);
+      const size_t m = xg ? v.xg.size() : v.xs.size(), n = yg ? v.yg.size() : v.ys.size(), kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+      if (m == 0 || n == 0) throw Panic("index out of bounds: rand[0]");
+      for (size_t i : p.idx) {
+        check(items[i], m, n);
+        auto app = [](Bytes& d, const Bytes& s) { d.insert(d.end(), s.begin(), s.end()); };
+        app(p.A, items[i].A);
+        app(p.B, items[i].B);
+        app(p.G, items[i].G);
+        app(p.T, cat(Ts[i]));
+      }
+      const size_t E = p.idx.size(), sx = xg ? cx.sz[2] : cx.sz[1], sy = yg ? cx.sz[3] : cx.sz[1];
+      assert_eq(p.A.size(), E * n * sx, "a_consts bytes");
+      assert_eq(p.B.size(), E * m * sy, "b_consts bytes");
+      assert_eq(p.G.size(), E * m * n * cx.sz[1], "gamma bytes");
+      p.pi.assign(E * kx * 2 * cx.sz[3], 0);
+      p.theta.assign(E * ky * 2 * cx.sz[2], 0);
+      cp[k] = gs_prove_part{(int)p.ty, E, (int)m, (int)n, (xg ? Xg : Xs).data(), (yg ? Yg : Ys).data(), p.A.data(),
+                            p.B.data(), p.G.data(), (xg ? Rg : Rs).data(), (yg ? Sg : Ss).data(), p.T.data(), nullptr,
+                            nullptr, p.pi.data(), p.theta.data(), 1};
+    }
+    cx.chk(gs_prove_mixed(cx.c, (int)cp.size(), cp.data()));
+    out.equ_proofs.resize(items.size());
+    for (const Part& p : ps) {
+      const size_t kx = xgroup(p.ty) ? 2 : 1, ky = ygroup(p.ty) ? 2 : 1;
+      auto pis = split<Com2>(p.pi, p.idx.size() * kx);
+      auto ths = split<Com1>(p.theta, p.idx.size() * ky);
+      for (size_t e = 0; e < p.idx.size(); e++)
+        out.equ_proofs[p.idx[e]] = EquProof{{pis.begin() + e * kx, pis.begin() + (e + 1) * kx},
+                                            {ths.begin() + e * ky, ths.begin() + (e + 1) * ky}, p.ty, Ts[p.idx[e]]};
+    }
+    return out;
+  }
+
+  // one verdict per equation, in the statement's order; the statement holds iff all are true
+  std::vector<bool> verify(const StatementProof& pr, const CRS& crs) const {
+    assert_eq(pr.equ_proofs.size(), items.size(), "proof.equ_proofs.len() == statement.len()");
+    const Ctx& cx = *crs.ctx;
+    std::vector<Part> ps = parts();
+    if (ps.size() > GS_MIXED_MAX) throw Panic("more equation types than a mixed call takes");
+    std::vector<gs_verify_part> cp(ps.size());
+    Bytes Cxg = cat(pr.com_xg.coms), Cyg = cat(pr.com_yg.coms), Cxs = cat(pr.com_xs.coms), Cys = cat(pr.com_ys.coms);
+    for (size_t k = 0; k < ps.size(); k++) {
+      Part& p = ps[k];
+      const bool xg = xgroup(p.ty), yg = ygroup(p.ty);
+      const size_t m = (xg ? pr.com_xg : pr.com_xs).coms.size(), n = (yg ? pr.com_yg : pr.com_ys).coms.size();
+      const size_t kx = xg ? 2 : 1, ky = yg ? 2 : 1;
+      if (m == 0 || n == 0) throw Panic("index out of bounds: empty commitment list");
+      const size_t tsz = p.ty == EquType::PairingProduct ? cx.sz[4] : p.ty == EquType::MultiScalarG1 ? cx.sz[2]
+                         : p.ty == EquType::MultiScalarG2 ? cx.sz[3] : cx.sz[1];
+      auto app = [](Bytes& d, const Bytes& s) { d.insert(d.end(), s.begin(), s.end()); };
+      for (size_t i : p.idx) {
+        check(items[i], m, n);
+        const EquProof& pf = pr.equ_proofs[i];
+        if (pf.equ_type != p.ty) throw Panic("assertion failed: equation type matches the proof's");
+        assert_eq(pf.pi.size(), kx, "pi.len()");
+        assert_eq(pf.theta.size(), ky, "theta.len()");
+        assert_eq(items[i].target.size(), tsz, "target size");
+        app(p.A, items[i].A);
+        app(p.B, items[i].B);
+        app(p.G, items[i].G);
+        app(p.target, items[i].target);
+        app(p.pi, cat(pf.pi));
+        app(p.theta, cat(pf.theta));
+      }
+      const size_t E = p.idx.size(), sx = xg ? cx.sz[2] : cx.sz[1], sy = yg ? cx.sz[3] : cx.sz[1];
+      assert_eq(p.A.size(), E * n * sx, "a_consts bytes");
+      assert_eq(p.B.size(), E * m * sy, "b_consts bytes");
+      assert_eq(p.G.size(), E * m * n * cx.sz[1], "gamma bytes");
+      assert_eq(p.pi.size(), E * kx * 2 * cx.sz[3], "pi bytes");
+      assert_eq(p.theta.size(), E * ky * 2 * cx.sz[2], "theta bytes");
+      assert_eq((xg ? Cxg : Cxs).size(), m * 2 * cx.sz[2], "xcoms bytes");
+      assert_eq((yg ? Cyg : Cys).size(), n * 2 * cx.sz[3], "ycoms bytes");
+      p.ok.assign(E, 0);
+      cp[k] = gs_verify_part{(int)p.ty, E, (int)m, (int)n, p.A.data(), p.B.data(), p.G.data(), p.target.data(),
+                             (xg ? Cxg : Cxs).data(), (yg ? Cyg : Cys).data(), p.pi.data(), p.theta.data(), p.ok.data(), 1};
+    }
+    cx.chk(gs_verify_mixed(cx.c, (int)cp.size(), cp.data()));
+    std::vector<bool> out(items.size(), false);
+    for (const Part& p : ps)
+      for (size_t e = 0; e < p.idx.size(); e++) out[p.idx[e]] = p.ok[e] != 0;
+    return out;
+  }
+};
+
 // ---- canonical wire format (ark-serialize; the derives at data_structures.rs:128,132, commit.rs:18,24,
 // prove.rs:55, statement.rs:117-179, generator.rs:35).  Framing here, element codecs in the library
 // (gs_wire_*).  serialize_compressed / serialize_uncompressed / deserialize_compressed<T> /

@@ -49,6 +49,21 @@ static Bytes section(std::ifstream& f) {
   return b;
 }
 
+// which variable group of a Statement a witness list belongs to, by its element type
+static void put_x(StatementVars& v, const std::vector<G1Affine>& x) { v.xg = x; }
+static void put_x(StatementVars& v, const std::vector<Fr>& x) { v.xs = x; }
+static void put_y(StatementVars& v, const std::vector<G2Affine>& y) { v.yg = y; }
+static void put_y(StatementVars& v, const std::vector<Fr>& y) { v.ys = y; }
+static const Commit1& com_x(const StatementProof& p, const std::vector<G1Affine>&) { return p.com_xg; }
+static const Commit1& com_x(const StatementProof& p, const std::vector<Fr>&) { return p.com_xs; }
+static const Commit2& com_y(const StatementProof& p, const std::vector<G2Affine>&) { return p.com_yg; }
+static const Commit2& com_y(const StatementProof& p, const std::vector<Fr>&) { return p.com_ys; }
+// (only reached for PPE cases, where the X witnesses ARE G1 points; the other overloads keep the template compiling)
+static G1Affine as_g1(const G1Affine& p) { return p; }
+static G1Affine as_g1(const Fr&) { return G1Affine{}; }
+static std::vector<G1Affine> as_g1v(const std::vector<G1Affine>& v) { return v; }
+static std::vector<G1Affine> as_g1v(const std::vector<Fr>&) { return {}; }
+
 template <class A1, class A2, class AT, EquType TY>
 static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const Bytes& Y, const Bytes& A, const Bytes& B,
                 const Bytes& G, const Bytes& tgt, const Bytes& R, const Bytes& S, const Bytes& T, const Bytes& xc,
@@ -180,6 +195,68 @@ static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const By
       CProof shortp = proof;
       shortp.equ_proofs[0].pi.pop_back();
       mc.verify_batch(std::vector<Equ>{equ, equ}, std::vector<CProof>{proof, shortp});
+    } catch (const Panic&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
+  // a Statement (statement.rs:24-28,109): equations over ONE list of variables, committed once.  Three equations of
+  // this case's type (the middle one with another Gamma) and -- for PPE cases -- an MSMEG1 over the same G1 variables
+  // and two fresh scalar variables: the statement's proofs equal Provable::prove per equation against the shared
+  // commitments under the same draws, its verdicts equal Verifiable::verify per equation, the first equation's proof
+  // is the golden one.
+  {
+    Equ other = equ;
+    other.gamma[0][0] = gflat[0].v == Bytes(fr, 0) ? rng_of({&R}).fr() : Fr{Bytes(fr, 0)};
+    Statement st;
+    st.push(equ);
+    st.push(other);
+    st.push(equ);
+    StatementVars v;
+    put_x(v, xvars);
+    put_y(v, yvars);
+    constexpr bool mix = TY == EquType::PairingProduct;
+    MSMEG1 e1;
+    std::vector<Fr> ys2;
+    if (mix) {
+      ReplayRng src = rng_of({&S, &R, &T});  // any scalars will do for the extra equation
+      ys2 = {src.fr(), src.fr()};
+      v.ys = ys2;
+      e1.a_consts = {as_g1(xvars[0]), as_g1(xvars[m - 1])};
+      for (uint32_t i = 0; i < m; i++) e1.b_consts.push_back(src.fr());
+      e1.gamma.assign(m, std::vector<Fr>{src.fr(), src.fr()});
+      e1.target = as_g1(xvars[0]);
+      st.push(e1);
+    }
+    // draw order of the statement: commit randomness of xg, yg, xs, ys, then T per equation
+    Bytes S2 = cat(std::vector<Fr>(ys2.size(), rng_of({&T}).fr()));  // randomness of the two extra scalar variables
+    ReplayRng rs = TY == EquType::MultiScalarG2 ? rng_of({&S, &R, &T, &T, &T})
+                   : mix                         ? rng_of({&R, &S, &S2, &T, &T, &T, &T})
+                                                 : rng_of({&R, &S, &T, &T, &T});
+    StatementProof sp = st.commit_and_prove(v, crs, rs);
+    CHECK(com_x(sp, xvars) == xcoms && com_y(sp, yvars) == ycoms);
+    CHECK(sp.equ_proofs.size() == st.size());
+    CHECK(cat(sp.equ_proofs[0].pi) == pi && cat(sp.equ_proofs[0].theta) == th);
+    CHECK(cat(sp.equ_proofs[2].pi) == pi && cat(sp.equ_proofs[2].theta) == th);
+    ReplayRng r1 = rng_of({&T});
+    EquProof single = other.prove(xvars, yvars, xcoms, ycoms, crs, r1);
+    CHECK(cat(sp.equ_proofs[1].pi) == cat(single.pi) && cat(sp.equ_proofs[1].theta) == cat(single.theta));
+    std::vector<bool> ok = st.verify(sp, crs);
+    CHECK(ok.size() == st.size() && ok[0] && ok[2]);
+    CHECK(ok[1] == other.verify(CProof{xcoms, ycoms, {sp.equ_proofs[1]}}, crs));
+    if (mix) {
+      ReplayRng r2 = rng_of({&T});
+      EquProof p1 = e1.prove(as_g1v(xvars), ys2, sp.com_xg, sp.com_ys, crs, r2);
+      CHECK(cat(sp.equ_proofs[3].pi) == cat(p1.pi) && cat(sp.equ_proofs[3].theta) == cat(p1.theta));
+      CHECK(sp.equ_proofs[3].equ_type == EquType::MultiScalarG1);
+      CHECK(ok[3] == e1.verify(CProof{sp.com_xg, sp.com_ys, {sp.equ_proofs[3]}}, crs));
+    }
+    bool threw = false;
+    try {
+      StatementProof bad = sp;
+      bad.equ_proofs[1].pi.pop_back();
+      st.verify(bad, crs);
     } catch (const Panic&) {
       threw = true;
     }
