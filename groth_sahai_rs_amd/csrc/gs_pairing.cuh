@@ -353,7 +353,10 @@ GS_HD_NOINLINE void multi_miller2(Fp12<C>& f0out, Fp12<C>& f1out, const Aff<Fq<C
 //             last lane-1 entry is any valid point: it is stepped and never consumed)
 //   qok       bit k: Q_k is not the identity (the same on both lanes)
 //   fixed[k]  line table of a CRS G2 argument (k >= nstep), consumed as in multi_miller
-// X::swap(l) returns the partner lane's line; both lanes of a pair always reach it together.
+// X::put(l) hands the lane's line to the exchange, X::get() returns the partner's; both lanes of a pair always reach
+// both together.  Two phases so that a policy that parks the line in memory (LDS) can fetch the partner's line AFTER the
+// lane's own line product: held in registers across that product (live set ~440 dwords) it would be spilled and
+// reloaded through the private segment, 84 dwords each way per step.
 template <class C, class X>
 GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const Aff<Fp2<C>>* qown, uint32_t qok,
                                       int nstep, int np, Proj2<C>* ts, const Line<C>* const* fixed, X& xch) {
@@ -378,8 +381,9 @@ GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const A
     for (int r = 0; r < rounds; r++) {
       const int ko = 2 * r + a, kp = 2 * r + 1 - a;
       miller_dbl(ts[r], l);
-      lp = xch.swap(l);
+      xch.put(l);
       if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
+      lp = xch.get();
       if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
     }
     for (int k = nstep; k < np; k++)
@@ -392,8 +396,9 @@ GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const A
         Aff<Fp2<C>> q = qown[r];
         if (d < 0) q.y = neg(q.y);
         miller_add(ts[r], l, q);
-        lp = xch.swap(l);
+        xch.put(l);
         if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
+        lp = xch.get();
         if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
       }
       for (int k = nstep; k < np; k++)
@@ -415,8 +420,9 @@ GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const A
           qf.y = neg(mul(q.y, frob_coeff<C>(2, 3)));
         }
         miller_add(ts[r], l, qf);
-        lp = xch.swap(l);
+        xch.put(l);
         if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
+        lp = xch.get();
         if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
       }
       for (int k = nstep; k < np; k++)

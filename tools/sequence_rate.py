@@ -1,3 +1,7 @@
+"""A SEQUENCE of bench configurations in ONE process (the Bench.run of bench.py): what profiles/r3/scratch_pool.txt
+was measured with -- a large batch must run at its stand-alone time whatever ran before it in the process.
+    python tools/sequence_rate.py m12 p12 m16 p16     (p = PPE, m = mixed 50/25/25; 12 / 16 = log2 equations;
+                                                       a trailing r = with the per-kernel profile pass)"""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import torch
