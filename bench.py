@@ -455,6 +455,85 @@ class Bench:
         }
 
 
+def inproc_main(args):
+    """`--gpus N --inproc`: the N-GPU configuration of configs[3] (2^18 equations cut into N contiguous blocks) driven
+    by ONE process through the C ABI's multi-GPU layer: gs_ctx_create_multi owns a shard (context + persistent host
+    thread) per device, the blocks are generated on their devices and stay there (gs_multi_prove_batch_dev /
+    gs_multi_verify_batch_dev), no data-path collective.  Same JSON line as the one-process-per-GPU mode; n_gpus = the
+    DISTINCT devices used."""
+    import numpy as np
+    import torch
+
+    import groth_sahai_rs_amd as gs
+    from groth_sahai_rs_amd.workload import Workload
+
+    nsh = max(args.gpus, 1)
+    shared = os.environ.get("GS_BENCH_SHARED") == "1"
+    devices = [0] * nsh if shared else list(range(nsh))
+    if not shared and torch.cuda.device_count() < nsh:
+        sys.stderr.write("bench.py: --gpus %d --inproc but %d device(s) visible\n" % (nsh, torch.cuda.device_count()))
+        sys.exit(3)
+    if not args.log2n:
+        args.log2n = 16 if nsh == 1 else max(18 - (nsh.bit_length() - 1), 10)
+    per = 1 << args.log2n
+    N = per * nsh
+    if not args.steps:
+        args.steps = max(3, min(200, int(12.0 * 135e3 / per)))
+    me = gs.MultiEngine(args.curve, devices, shared_devices=shared)
+    blocks = [me.shard(N, i) for i in range(nsh)]
+    assert all(hi - lo == per for lo, hi in blocks)
+    # one generator engine per distinct device builds that device's blocks with the library's own helper kernels (the
+    # same seed everywhere: one CRS for all shards)
+    gens, wls = {}, []
+    for i, d in enumerate(devices):
+        if d not in gens:
+            gens[d] = gs.Engine(args.curve, d)
+        wls.append(Workload(gens[d], ty=args.type, N=per, m=args.m, n=args.n, seed=20241220 + 1, device="cuda:%d" % d))
+    me.set_crs(wls[0].crs)
+    col = lambda k: [getattr(w, k) for w in wls]
+
+    def step():
+        me.prove_batch_dev(args.type, N, args.m, args.n, col("X"), col("Y"), col("A"), col("B"), col("Gamma"), col("R"),
+                           col("S"), col("T"), col("xcoms"), col("ycoms"), col("pi"), col("theta"))
+        me.verify_batch_dev(args.type, N, args.m, args.n, col("A"), col("B"), col("Gamma"), col("target"), col("xcoms"),
+                            col("ycoms"), col("pi"), col("theta"), col("ok"))
+        me.sync()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    dt = time.perf_counter() - t0
+    assert all(w.ok.cpu().numpy().all() for w in wls), "a valid benchmark batch was rejected"
+    for w in wls:  # corrupted proofs are found, per shard
+        bad = set(w.corrupt())
+    me.verify_batch_dev(args.type, N, args.m, args.n, col("A"), col("B"), col("Gamma"), col("target"), col("xcoms"),
+                        col("ycoms"), col("pi"), col("theta"), col("ok"))
+    me.sync()
+    for w in wls:
+        ok = w.ok.cpu().numpy()
+        assert ok.tolist() == [0 if i in bad else 1 for i in range(w.N)], "verification verdicts wrong"
+    res = {"metric": "GS proofs+verifies/sec (BLS12-381 PPE batch)" if args.curve == 0 and args.type == 0 else
+           "GS proofs+verifies/sec (curve %d type %d)" % (args.curve, args.type),
+           "value": N * args.steps / dt, "unit": "proofs+verifies/s", "n_gpus": len(set(devices)), "steps": args.steps,
+           "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong" if nsh > 1 else "weak", "vs_baseline": None,
+           "dtype": "u32 limbs (381-bit Montgomery)" if args.curve == 0 else "u32 limbs (254-bit Montgomery)",
+           "data": "synthetic",
+           "config": {"workload": "2^%d independent equations per shard, m=%d n=%d, commit_and_prove+verify(exact), one "
+                                  "process, gs_ctx_create_multi + gs_multi_*_dev" % (args.log2n, args.m, args.n),
+                      "shards": nsh, "devices": devices, "total_equations": N,
+                      "parallelism": "equation-sharded x%d inside one process (persistent per-device threads, no "
+                                     "collective)" % nsh}}
+    print(json.dumps(res))
+    me.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,11 +548,17 @@ def main():
     ap.add_argument("--mode", choices=["exact", "rlc"], default="exact",
                     help="verifier: exact = reference semantics (bool per equation); rlc = batched pairing-product check")
     ap.add_argument("--mixed", action="store_true", help="configs[2]: 50%% PPE, 25%% MSMEG1, 25%% MSMEG2")
+    ap.add_argument("--inproc", action="store_true",
+                    help="with --gpus N: ONE process drives the N GPUs through gs_ctx_create_multi and the device-pointer "
+                         "family (gs_multi_*_dev: shards resident on their devices, persistent per-device threads) "
+                         "instead of one process per GPU; GS_BENCH_SHARED=1 puts the N shards on GPU 0 (rehearsal)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other single-GPU configurations")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU-baseline sample units (0 = auto, ~20 s)")
     args = ap.parse_args()
 
+    if args.inproc:
+        return inproc_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)  # never returns
 

@@ -111,6 +111,26 @@ def test_bench_two_rank_rehearsal(mode, launch):
     assert line["roofline"]["alu"]["frac"] > 0
 
 
+def test_bench_inproc_rehearsal():
+    """`bench.py --gpus 3 --inproc`: ONE process drives the shards through gs_ctx_create_multi and the device-pointer
+    family (gs_multi_prove_batch_dev / _verify_batch_dev, persistent per-shard threads).  On a one-GPU box the three
+    shards sit on GPU 0 (GS_BENCH_SHARED=1); the line must report the DISTINCT devices used, the block sizes and the
+    strong-scaling contract, and the corrupted proofs of every shard must have been found (asserted inside)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, GS_BENCH_SHARED="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "3", "--inproc", "--steps", "1", "--warmup", "1",
+           "--log2n", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["shards"] == 3 and line["config"]["devices"] == [0, 0, 0]
+    assert line["config"]["total_equations"] == 768 and line["scaling"] == "strong"
+    assert line["value"] == pytest.approx(768 / (line["ms_per_step"] / 1e3), rel=1e-6)
+
+
 def test_bench_refuses_fewer_ranks_than_requested():
     """--gpus 4 under a 2-rank launch is an error (exit code 3), not a silently smaller job."""
     import subprocess
