@@ -59,6 +59,11 @@ def test_mixed_batch_equals_one_call_per_sub_batch():
         oks = eng.verify_mixed(vparts)
         assert oks[0].all() and oks[1].all() and oks[3].all() and oks[2][:69].all() and oks[2][69] == 0
     eng.prof_enable(False)
+    # six parts in one call: more parts than a merged launch has segments (4), so every body goes out in two launches
+    got6 = eng.prove_mixed((parts * 2)[:6])
+    for g, w in zip(got6, (want * 2)[:6]):
+        for k in OUT_P:
+            assert (g[k] == w[k]).all(), ("six parts", k)
     # device pointers: the workloads' own tensors, outputs zeroed first
     for wl in wls:
         for k in OUT_P:
