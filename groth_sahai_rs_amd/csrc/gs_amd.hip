@@ -1219,7 +1219,10 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     c->work_hint = N * sp.var.size();  // terms
     // the lanes' Straus tables: lane-contiguous global workspace (see jac_msm_straus_at), at most VAR_WS_LANES lanes
     // of it; a larger batch goes in several launches over the same workspace
-    const int tmax = sp.tm <= 4 ? 4 : 8;
+    // (a part of a mixed call always takes the 8-term instance, which runs shorter groups just as well, so that parts
+    // whose window width agrees share a launch; parts that differ in window width or outputs per build still go out
+    // separately -- at 2^12 mixed that is one extra launch of ~3 ms)
+    const int tmax = (c->rec || sp.tm > 4) ? 8 : 4;
     const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes : var_ws_default(c));
     void* tabws;
     RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * (sizeof(Aff<F>) + sizeof(Jac<F>)), &tabws));
