@@ -10,6 +10,6 @@ class A: pass
 b = bench.Bench(A(), None, 0, 1, 0, "cuda:0", "cuda:0")
 seq = sys.argv[1:]
 for s in seq:
-    kw = dict(p12=dict(log2n=12), m12=dict(log2n=12, mixed=True), p16=dict(log2n=16), m16=dict(log2n=16, mixed=True), p12r=dict(log2n=12, roofline=True), m12r=dict(log2n=12, mixed=True, roofline=True))[s]
+    kw = dict(p10=dict(log2n=10), m10=dict(log2n=10, mixed=True), p8=dict(log2n=8), p14=dict(log2n=14), p12=dict(log2n=12), m12=dict(log2n=12, mixed=True), p16=dict(log2n=16), m16=dict(log2n=16, mixed=True), p12r=dict(log2n=12, roofline=True), m12r=dict(log2n=12, mixed=True, roofline=True))[s]
     r = b.run(steps=3, warmup=1, seed_off=3, **kw)
     print(s, round(r["value"]), round(r["ms_per_step"], 1), flush=True)
