@@ -1721,7 +1721,9 @@ template <class C> struct Impl {
     const bool twin = mode != 0;
     // the Gamma^T c lanes: Straus groups with their own tables, or (large arities: every base serves 2 n outputs)
     // lanes over shared per-base window tables -- measured in profiles/r3/large_arity_334.json
-    const bool tab8 = c->var_tab == 1 || (c->var_tab < 0 && wide_prep(m, n) && n >= 32);
+    // (planned only while the tables -- N x 2 m bases x 128 entries, affine + Jacobian staging -- stay below 8 GB)
+    const double tab8_bytes = (double)N * 2.0 * m * 128.0 * (double)(sizeof(A1) + sizeof(Jac<F1>));
+    const bool tab8 = c->var_tab == 1 || (c->var_tab < 0 && wide_prep(m, n) && n >= 32 && tab8_bytes <= 8e9);
     build_verify(vp, c->curve, ty, m, n, pm, budget, twin, tab8 ? -1 : pick_tm(c, fillN(c, N), m, 2 * n, false, n),
                  c->line_tables);
     // G1-side points

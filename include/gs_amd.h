@@ -109,7 +109,9 @@ int gs_sizes(int curve_id, size_t out[6]);
  *     shape (G2, 8 terms, 5-bit windows), ~6 GB in total for the 2^16 PPE shapes;
  *   - host-pointer entry points only: a pinned host buffer and device staging of the call's input + output bytes each
  *     (0.45 GB for a 2^16 PPE prove);
- *   - large arities only: the shared per-base window tables, N x 2 m x 128 entries (14 KB per base in G1).
+ *   - large arities only: the shared per-base window tables, N x 2 m bases x 128 entries (affine + Jacobian staging:
+ *     36 KB per base in G1; planned only while that stays below 8 GB);
+ *   - mixed calls: the above once per PART (the parts' scratch is live at the same time).
  * A pool of W worker contexts on one GPU therefore costs 1.8 GB + W x (the above for the workers' batch size). */
 int gs_set_crs(gs_ctx* ctx, const void* crs_host);
 
