@@ -88,9 +88,9 @@ template <class C> GS_ML void miller_add(Proj2<C>& t, Line<C>& l, const Aff<Fp2<
   t.z = mul(t.z, e);
 }
 
-// Lines evaluated at P go into the accumulator in PAIRS on BN254 (f12_mul_by_lines2: 23 instead of 26 Fp2
-// multiplications per two lines); a line left over is held until the next one arrives or the accumulator is needed (before its next
-// squaring / at the end), where it goes in on its own.
+// Lines evaluated at P can go into the accumulator in PAIRS (f12_mul_by_lines2: 23 instead of 26 Fp2 multiplications per
+// two lines; a line left over is held until the next one arrives or the accumulator is needed -- before its next squaring /
+// at the end -- where it goes in on its own).  Off since round 3 (see pair_lines below); kept for GS_LINES2_ALL.
 template <class C> struct LineAcc {
   ELine<C> pend;
   bool has = false;
@@ -101,7 +101,12 @@ template <class C> struct LineAcc {
 #elif defined(GS_LINES2_NONE)
     constexpr bool pair_lines = false;
 #else
-    constexpr bool pair_lines = C::IS_BN;
+    // Round 3: never.  With the lane-pair kernel and the dot-product form of the sparse product in its register-friendly
+    // call order (gs_tower.cuh) the unpaired form wins on BOTH curves: BN254 k_miller.pairdpp 107.8 -> 100.9 ms at 2^16
+    // (`profiles/r3/ab_nolines2_bn254.txt`), BLS12-381 157.4-158.8 ms unpaired against 164.8-165.2 ms paired
+    // (`profiles/r3/ab_lines2_bls.txt`).  GS_LINES2_ALL brings the paired form back (round 1-2: it took 8 % off the
+    // BN254 twin kernel).
+    constexpr bool pair_lines = false;
 #endif
     // (round 2, with the dot-product form of the sparse product: BN254 paired 130.4 ms, unpaired 130.9 ms at 2^16)
     if (!pair_lines) {  // measured on gfx950: pairing is a wash on BLS12-381 (the sparse product is the more
