@@ -381,19 +381,28 @@ class Bench:
         host = lambda t: t.cpu().numpy()
         X, Y, A, B, G, R, S, T, tgt = [host(getattr(wl, k)) for k in ("X", "Y", "A", "B", "Gamma", "R", "S", "T", "target")]
 
-        def host_step():
-            o = eng.prove_batch(0, N, m, n, X, Y, A, B, G, R, S, T)
-            ok = eng.verify_batch(0, N, m, n, A, B, G, tgt, o["xcoms"], o["ycoms"], o["pi"], o["theta"])
-            return o, ok
+        # the caller keeps its result buffers from call to call, as a Rust caller reusing its Vecs does (arrays made
+        # per call are first touched inside the call: ~30 ms of page faults at 2^16, profiles/r3/hostpipe/)
+        sh = eng.shape(0)
+        o = {"xcoms": np.zeros(N * m * eng.COM1, dtype=np.uint8), "ycoms": np.zeros(N * n * eng.COM2, dtype=np.uint8),
+             "pi": np.zeros(N * sh["kx"] * eng.COM2, dtype=np.uint8), "theta": np.zeros(N * sh["ky"] * eng.COM1, dtype=np.uint8)}
+        okbuf = np.zeros(N, dtype=np.uint8)
 
-        for _ in range(2):  # warm-up: pinned and device staging grow, the copy workers and streams come up
-            o, ok = host_step()
-        assert ok.all()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            o, ok = host_step()
-        dt_h = (time.perf_counter() - t0) / steps
+        def host_step():
+            eng.prove_batch(0, N, m, n, X, Y, A, B, G, R, S, T, out=o)
+            return eng.verify_batch(0, N, m, n, A, B, G, tgt, o["xcoms"], o["ycoms"], o["pi"], o["theta"], ok=okbuf)
+
+        def host_rate():
+            for _ in range(2):  # warm-up: pinned and device staging grow, the copy workers and streams come up
+                ok = host_step()
+            assert ok.all()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ok = host_step()
+            return (time.perf_counter() - t0) / steps
+
+        dt_h = host_rate()
         wl.step()
         eng.sync()
         t0 = time.perf_counter()
@@ -401,7 +410,16 @@ class Bench:
             wl.step()
         eng.sync()
         dt_d = (time.perf_counter() - t0) / steps
-        assert ok.all() and wl.ok.cpu().numpy().all() and (o["pi"] == host(wl.pi)).all()
+        assert okbuf.all() and wl.ok.cpu().numpy().all() and (o["pi"] == host(wl.pi)).all()
+        # the same arrays page-locked once (gs_host_register): DMA straight from / to them, no staging copy
+        regs = [X, Y, A, B, G, R, S, T, tgt, okbuf] + list(o.values())
+        for a in regs:
+            eng.host_register(a)
+        o["pi"][:] = 0
+        dt_p = host_rate()
+        assert okbuf.all() and (o["pi"] == host(wl.pi)).all()
+        for a in regs:
+            eng.host_unregister(a)
         nbytes = sum(a.nbytes for a in (X, Y, A, B, G, R, S, T, tgt)) + sum(v.nbytes for v in o.values()) * 2 + \
             A.nbytes + B.nbytes + G.nbytes + N
         del wl
@@ -409,8 +427,10 @@ class Bench:
         return {"value": N / dt_h, "ms_per_step": dt_h * 1e3, "steps": steps,
                 "device_resident_value": N / dt_d, "device_resident_ms_per_step": dt_d * 1e3,
                 "ratio_to_device_resident": dt_d / dt_h, "pcie_bytes_per_step": int(nbytes),
+                "page_locked": {"value": N / dt_p, "ms_per_step": dt_p * 1e3, "ratio_to_device_resident": dt_d / dt_p},
                 "workload": "2^%d PPE m=%d n=%d BLS12-381 through gs_prove_batch + gs_verify_batch (pageable host arrays "
-                            "in and out, pinned staging pipeline inside the library)" % (log2n, m, n)}
+                            "in, result arrays the caller keeps; pinned staging pipeline inside the library; "
+                            "page_locked: the same arrays registered once with gs_host_register)" % (log2n, m, n)}
 
     def describe(self, log2n, curve, ty, mixed, mode, m, n):
         return "2^%d independent %s equations per GPU, m=%d n=%d, %s, commit_and_prove+verify(%s)" % (

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/gs_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "gs_ctx_create", "gs_ctx_destroy", "gs_set_stream", "gs_set_option", "gs_sync", "gs_last_error", "gs_version", "gs_sizes",
+    "gs_ctx_create", "gs_ctx_destroy", "gs_set_stream", "gs_set_option", "gs_sync", "gs_host_register",
+    "gs_host_unregister", "gs_last_error", "gs_version", "gs_sizes",
     "gs_set_crs", "gs_crs_generate", "gs_crs_generate_hiding",
     "gs_commit_g1_dev", "gs_commit_g2_dev", "gs_commit_fr_b1_dev", "gs_commit_fr_b2_dev",
     "gs_commit_g1", "gs_commit_g2", "gs_commit_fr_b1", "gs_commit_fr_b2",
@@ -154,6 +155,14 @@ class Engine:
     def sync(self):
         self._chk(self.lib.gs_sync(self.ctx))
 
+    def host_register(self, arr):
+        """Page-lock a numpy array the caller reuses across host-pointer calls (gs_host_register): the pipeline then
+        moves it by DMA directly, without the staging copy."""
+        self._chk(self.lib.gs_host_register(self.ctx, ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes)))
+
+    def host_unregister(self, arr):
+        self._chk(self.lib.gs_host_unregister(self.ctx, ctypes.c_void_p(arr.ctypes.data)))
+
     def set_option(self, key, value):
         """Planner override (include/gs_amd.h, gs_set_option): miller_twin, miller_ch, var_tm, var_mo, var_w, red_k, coop_fe, line_tables,
         overlap.  Results never change, only which kernel shapes run."""
@@ -219,23 +228,33 @@ class Engine:
         self._chk(fn(self.ctx, ctypes.c_size_t(n), _p(v), _p(r), _p(out)))
         return out.reshape(n, osz)
 
-    def prove_batch(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, want_coms=True):
+    def prove_batch(self, ty, N, m, n, X, Y, A, B, Gamma, R, S, T, want_coms=True, out=None):
+        """`out`: dict of preallocated uint8 arrays xcoms, ycoms, pi, theta to write into (e.g. page-locked ones)."""
         sh = self.shape(ty)
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         X, Y, A, B, Gamma, R, S, T = map(u8, (X, Y, A, B, Gamma, R, S, T))
         self._check_prove("gs_prove_batch", ty, N, m, n, X, Y, A, B, Gamma, R, S, T)
-        xc = self._out(N * m * self.COM1) if want_coms else None
-        yc = self._out(N * n * self.COM2) if want_coms else None
-        pi = self._out(N * sh["kx"] * self.COM2)
-        th = self._out(N * sh["ky"] * self.COM1)
+        if out is not None:
+            xc, yc, pi, th = (out.get(k) for k in ("xcoms", "ycoms", "pi", "theta"))
+            _need("gs_prove_batch", [("xcoms", xc, N * m * self.COM1), ("ycoms", yc, N * n * self.COM2),
+                                     ("pi", pi, N * sh["kx"] * self.COM2), ("theta", th, N * sh["ky"] * self.COM1)])
+            if pi is None or th is None:
+                raise GsError(3, "gs_prove_batch: out needs pi and theta")
+        else:
+            xc = self._out(N * m * self.COM1) if want_coms else None
+            yc = self._out(N * n * self.COM2) if want_coms else None
+            pi = self._out(N * sh["kx"] * self.COM2)
+            th = self._out(N * sh["ky"] * self.COM1)
         self._chk(self.lib.gs_prove_batch(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(X)), _p(u8(Y)), _p(u8(A)),
                                           _p(u8(B)), _p(u8(Gamma)), _p(u8(R)), _p(u8(S)), _p(u8(T)), _p(xc), _p(yc),
                                           _p(pi), _p(th)))
         return dict(xcoms=xc, ycoms=yc, pi=pi, theta=th)
 
-    def verify_batch(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta):
+    def verify_batch(self, ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta, ok=None):
         u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-        ok = np.zeros(N, dtype=np.uint8)
+        if ok is None:
+            ok = np.zeros(N, dtype=np.uint8)
+        _need("gs_verify_batch", [("ok", ok, N)])
         A, B, Gamma, target, xcoms, ycoms, pi, theta = map(u8, (A, B, Gamma, target, xcoms, ycoms, pi, theta))
         self._check_verify("gs_verify_batch", ty, N, m, n, A, B, Gamma, target, xcoms, ycoms, pi, theta)
         self._chk(self.lib.gs_verify_batch(self.ctx, ty, ctypes.c_size_t(N), m, n, _p(u8(A)), _p(u8(B)),

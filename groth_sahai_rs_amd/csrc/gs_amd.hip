@@ -291,7 +291,23 @@ struct HostPipe {
     size_t bytes = 0, off = 0;
     std::atomic<int> left{0};
     bool enq = false;
+    bool direct = false;  // the caller's array is page-locked already: DMA to / from it, no staging copy
   };
+  // Page-locked host memory (hipHostMalloc, hipHostRegister / gs_host_register, a torch pinned tensor) is recognised
+  // per array: both ends of the array must lie in it.
+  static bool host_pinned(const void* p, size_t bytes) {
+    static const bool off = getenv("GS_PIPE_NO_DIRECT") != nullptr;
+    if (off || !p || !bytes) return false;
+    for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + bytes - 1}) {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: "invalid value" on some runtimes, "unregistered" on others
+        return false;
+      }
+      if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+  }
   gs_ctx* c;
   Arr arr[16];
   hipEvent_t ev1[16] = {nullptr}, ev2[16] = {nullptr};
@@ -326,6 +342,8 @@ struct HostPipe {
     size_t total = 0;
     for (int i = 0; i < n; i++) {
       if (!arr[i].bytes) continue;
+      arr[i].direct = host_pinned(arr[i].hin ? arr[i].hin : arr[i].hout, arr[i].bytes);
+      if (arr[i].direct) continue;
       arr[i].off = total;
       total += (arr[i].bytes + 255) & ~(size_t)255;
     }
@@ -349,8 +367,15 @@ struct HostPipe {
     t0 = std::chrono::steady_clock::now();
     trace = getenv("GS_PIPE_TRACE") != nullptr;
     if (const char* e = getenv("GS_COPY_SPLIT")) split = std::max(1, std::min(2, atoi(e)));
+    // The copy streams are created at HIGH priority, which is not about urgency: the runtime multiplexes the streams
+    // of one priority level over a few hardware queues (4 by default), and a copy stream that lands on the compute
+    // stream's queue is serialized with the kernels there -- the first kernel then starts only after EVERY upload
+    // enqueued before it, and uploads enqueued behind a long kernel wait for that kernel
+    // (profiles/r3/host_pipe_timeline.txt).  Another priority level is another set of queues.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (hipStream_t* st : {&c->copy_stream, &c->copy_stream2, &c->copy_out_stream, &c->copy_out_stream2})
-      if (!*st) HIPCHK(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+      if (!*st) HIPCHK(c, hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest));
     if (!c->pev_ready) HIPCHK(c, hipEventCreateWithFlags(&c->pev_ready, hipEventDisableTiming));
     if (!c->pool) {
       int nt = 4;
@@ -370,7 +395,13 @@ struct HostPipe {
     }
     for (int k = 0; k < norder; k++) {
       Arr& a = arr[order[k]];
-      if (a.hin) c->pool->submit((uint8_t*)c->pin + a.off, a.hin, a.bytes, &a.left);
+      if (a.hin && !a.direct) c->pool->submit((uint8_t*)c->pin + a.off, a.hin, a.bytes, &a.left);
+    }
+    for (int k = 0; k < norder; k++) {  // page-locked inputs need no staging: their uploads go out at once
+      Arr& a = arr[order[k]];
+      if (!a.hin || !a.direct || a.enq) continue;
+      RC(xfer(a.d, a.hin, a.bytes, hipMemcpyHostToDevice, c->copy_stream, c->copy_stream2, ev1[order[k]], ev2[order[k]]));
+      a.enq = true;
     }
     c->pipe = this;
     if (trace) fprintf(stderr, "[pipe] %7.2f ms begin done (%zu bytes of staging)\n", ms(), total);
@@ -402,7 +433,7 @@ struct HostPipe {
         double w0 = trace ? ms() : 0;
         CopyPool::wait(&a.left);
         double w1 = trace ? ms() : 0;
-        RC(xfer(a.d, (uint8_t*)c->pin + a.off, a.bytes, hipMemcpyHostToDevice, c->copy_stream, c->copy_stream2, ev1[i],
+        RC(xfer(a.d, a.direct ? a.hin : (uint8_t*)c->pin + a.off, a.bytes, hipMemcpyHostToDevice, c->copy_stream, c->copy_stream2, ev1[i],
                 ev2[i]));
         a.enq = true;
         if (trace)
@@ -428,7 +459,7 @@ struct HostPipe {
         HIPCHK(c, hipStreamWaitEvent(c->copy_out_stream2, c->pev_ready, 0));
         first = false;
       }
-      RC(xfer((uint8_t*)c->pin + a.off, a.d, a.bytes, hipMemcpyDeviceToHost, c->copy_out_stream, c->copy_out_stream2,
+      RC(xfer(a.direct ? a.hout : (uint8_t*)c->pin + a.off, a.d, a.bytes, hipMemcpyDeviceToHost, c->copy_out_stream, c->copy_out_stream2,
               ev1[i], ev2[i]));
       a.enq = true;
       out_order[n_out++] = i;
@@ -450,7 +481,7 @@ struct HostPipe {
       Arr& a = arr[i];
       HIPCHK(c, hipEventSynchronize(ev1[i]));
       if (trace) fprintf(stderr, "[pipe] %7.2f ms array %d arrived\n", ms(), i);
-      c->pool->submit(a.hout, (uint8_t*)c->pin + a.off, a.bytes, &a.left);
+      if (!a.direct) c->pool->submit(a.hout, (uint8_t*)c->pin + a.off, a.bytes, &a.left);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) CopyPool::wait(&arr[i].left);
@@ -2437,6 +2468,39 @@ int gs_sync(gs_ctx* c) {
   return GS_OK;
 }
 const char* gs_last_error(gs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// Page-lock a caller's buffer (a Vec the Rust side reuses from call to call): the host-pointer entry points then move
+// it by DMA directly instead of through the staging copy.  The runtime counts registrations of a range silently; the
+// library keeps its own list so that a second registration, or the release of an unknown pointer, is an error.
+static std::mutex g_reg_mu;
+static std::map<void*, size_t> g_reg;
+int gs_host_register(gs_ctx* c, void* ptr, size_t bytes) {
+  RC(check_ctx(c, false));
+  if (!ptr || !bytes) return GS_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  if (g_reg.count(ptr)) return fail(c, GS_ERR_ARG, "gs_host_register: already registered");
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, e == hipErrorOutOfMemory ? GS_ERR_ALLOC : GS_ERR_ARG, "hipHostRegister", e);
+  }
+  g_reg[ptr] = bytes;
+  return GS_OK;
+}
+int gs_host_unregister(gs_ctx* c, void* ptr) {
+  RC(check_ctx(c, false));
+  if (!ptr) return GS_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  if (!g_reg.count(ptr)) return fail(c, GS_ERR_ARG, "gs_host_unregister: not registered here");
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // nothing of this context may still be moving the buffer
+  hipError_t e = hipHostUnregister(ptr);
+  g_reg.erase(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, GS_ERR_ARG, "hipHostUnregister", e);
+  }
+  return GS_OK;
+}
 
 int gs_set_crs(gs_ctx* c, const void* crs) {
   RC(check_ctx(c, false));

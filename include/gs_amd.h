@@ -92,6 +92,17 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  * roctx library for phase markers ("gs.prove", "gs.prove.g1", "gs.verify.miller" ...) even when no profiler mapped it. */
 int gs_set_option(gs_ctx* ctx, const char* key, int value);
 int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the context's stream */
+/* Page-locked caller memory.  The host-pointer entry points below (gs_prove_batch, gs_verify_batch, the mixed and the
+ * Statement calls, gs_multi_*) stage pageable arrays through a pinned buffer of their own (one memcpy per array and
+ * direction on worker threads).  An array that already lies in page-locked memory -- hipHostMalloc, hipHostRegister,
+ * or a buffer registered here -- is recognised per array (both of its ends are looked up) and moved by DMA straight
+ * from / to the caller's memory: no staging copy, uploads start at once, and the call reaches the device-resident
+ * rate within 1-2 % (profiles/r3/host_path_rate.txt).  A Rust caller registers the Vecs it reuses across calls once
+ * (registration costs about as much as copying the buffer a few times).  [prove.rs:29-52 / verifier.rs:18-21 take
+ * slices; this is the cheap way to hand them over]
+ * gs_host_unregister waits for the context's stream first.  GS_ERR_ARG: null / empty / already registered / unknown. */
+int gs_host_register(gs_ctx* ctx, void* ptr, size_t bytes);
+int gs_host_unregister(gs_ctx* ctx, void* ptr);
 const char* gs_last_error(gs_ctx* ctx);
 const char* gs_version(void);
 /* sizes in bytes of the boundary PODs for a curve: out[0..5] = Fq, Fr, G1, G2, GT, CRS */

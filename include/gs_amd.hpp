@@ -68,6 +68,19 @@ struct Ctx {
   }
 };
 
+// A caller's buffer page-locked for as long as the object lives (gs_host_register): batches handed over in it are
+// moved by DMA directly instead of through the library's staging copy.
+class PinnedRegion {
+  const Ctx& ctx_;
+  void* p_;
+
+ public:
+  PinnedRegion(const Ctx& ctx, void* p, size_t bytes) : ctx_(ctx), p_(p) { ctx_.chk(gs_host_register(ctx_.c, p, bytes)); }
+  PinnedRegion(const PinnedRegion&) = delete;
+  PinnedRegion& operator=(const PinnedRegion&) = delete;
+  ~PinnedRegion() { gs_host_unregister(ctx_.c, p_); }
+};
+
 template <class T> inline Bytes cat(const std::vector<T>& xs) {
   Bytes o;
   for (const T& x : xs) o.insert(o.end(), x.v.begin(), x.v.end());

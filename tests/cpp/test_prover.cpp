@@ -180,6 +180,16 @@ static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const By
     CHECK(!other.verify(proof, crs));
   }
 
+  // page-locked caller memory: the region registers and releases; registering it twice, or releasing it twice, is refused
+  {
+    Bytes buf(1 << 16, 0);
+    {
+      PinnedRegion pr(*crs.ctx, buf.data(), buf.size());
+      CHECK(gs_host_register(crs.ctx->c, buf.data(), buf.size()) != GS_OK);
+    }
+    CHECK(gs_host_unregister(crs.ctx->c, buf.data()) != GS_OK);
+  }
+
   // the several-GPU entry (gs_ctx_create_multi; one device on this box): a batch of three proofs of the same
   // statement, the middle one tampered -- verdicts per equation as Verifiable::verify gives them
   {
