@@ -513,10 +513,11 @@ struct MCost {
 #ifndef GS_PLAN_PAIR
 #define GS_PLAN_PAIR 1
 #endif
-// (profiles/r2/fq_mul_counts.json: miller*_per_lane, _per_pair / _per_triple, _per_fixed_pair / _per_fixed_triple)
+// (profiles/r3/fq_mul_counts.json: miller*_per_lane, _per_pair / _per_triple, _per_fixed_pair / _per_fixed_triple --
+// the counts of the unpaired line products both curves use since round 3)
 static inline MCost mcost(int curve, bool twin) {
-  if (curve == 0) return twin ? MCost{4536.0, 7356.0, 5848.0} : MCost{2268.0, 4432.0, 2924.0};
-  return twin ? MCost{4680.0, 9991.0, 7568.0} : MCost{2340.0, 6207.0, 3784.0};
+  if (curve == 0) return twin ? MCost{4536.0, 7764.0, 6256.0} : MCost{2268.0, 4636.0, 3128.0};
+  return twin ? MCost{4680.0, 10519.0, 8096.0} : MCost{2340.0, 6471.0, 4048.0};
 }
 static inline bool pair_fixed(bool lt, const PairRef& r) { return lt && r.q_arr == 2; }  // Q array 2 = CRS (v, W2)
 // Split one cell's pairs into the fewest tasks whose lane cost stays within `budget`: costly pairs first, each to the
@@ -577,9 +578,17 @@ static double fold_cost(double n, double unit) {
   return c + n * unit;
 }
 // `pair`: the twin task list run by k_miller_pair -- two lanes of half the length per (equation, task)
+// A pair of lanes (k_miller_pair) is one task inside ONE wave: what the wave executes per loop digit is a squaring, one
+// twist-point step per ROUND of two stepping triples (the lanes of a pair step one each; an odd triple is a round of its
+// own) and one line product per triple.
+static inline double pair_lane_cost(const gs_ctx* c, const MillerTask& t) {
+  const MCost mc = mcost(c->curve, true);
+  int nv = 0, nf = 0;
+  for (int q = 0; q < t.np; q++) (pair_fixed(c->line_tables, t.pr[q]) ? nf : nv)++;
+  return mc.base / 2 + ((nv + 1) / 2) * (mc.var - mc.fix) + (nv + nf) * mc.fix / 2;
+}
 static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTask>& mt, bool twin, bool pair = false) {
   MCost mc = mcost(c->curve, twin);
-  if (pair) mc = MCost{mc.base / 2, mc.var / 2, mc.fix / 2};
   // Lanes are task-major: a wave is 64 equations of ONE task and lasts as long as that task's lane.  A launch lasts
   // as long as its longest lane, or -- once it is several rounds of waves -- as long as all lanes together take on the
   // SIMD slots (waves of short tasks do not wait for those of long ones).
@@ -590,6 +599,7 @@ static double miller_cost(const gs_ctx* c, size_t N, const std::vector<MillerTas
   for (const MillerTask& t : mt) {
     double l = mc.base;
     for (int q = 0; q < t.np; q++) l += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix : mc.var;
+    if (pair) l = pair_lane_cost(c, t);
     longest = l > longest ? l : longest;
     all += l * wpt;
   }
@@ -1044,6 +1054,9 @@ static void share_tables(const gs_ctx* c, size_t N, SidePlan& sp, bool g2) {
     for (auto& f : fam) lanes += (f.size() + mo - 1) / mo;
     for (int w : {4, 5}) {
       if (c->var_w > 0 && w != c->var_w) continue;
+      // a part of a mixed call: one window width for every part, or their Straus lanes are two kernel instances and go
+      // out as two under-filled launches (2^12 mixed: 3.1 + 4.7 ms where one launch takes 4.7)
+      if (c->var_w <= 0 && c->rec && w != 4) continue;
       double rounds = wave_rounds(c, (double)N * lanes / 64.0, g2);
       int eff_mo = (int)std::min((size_t)mo, share);
       double cost = rounds * straus_lane_cost(g2, c->curve == 1, ntmax, eff_mo, w);
@@ -1250,10 +1263,10 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     c->work_hint = N * sp.var.size();  // terms
     // the lanes' Straus tables: lane-contiguous global workspace (see jac_msm_straus_at), at most VAR_WS_LANES lanes
     // of it; a larger batch goes in several launches over the same workspace
-    // (a part of a mixed call always takes the 8-term instance, which runs shorter groups just as well, so that parts
-    // whose window width agrees share a launch; parts that differ in window width or outputs per build still go out
-    // separately -- at 2^12 mixed that is one extra launch of ~3 ms)
-    const int tmax = (c->rec || sp.tm > 4) ? 8 : 4;
+    // (parts of a mixed call share a launch when they agree on the instance: the window width is fixed for them in
+    // share_tables; the 4- or 8-term instance follows the part's own group size -- the 8-term one runs 4-term groups
+    // too, but 1.8x slower (2^12 mixed: 5.6 against 3.1 ms), so parts are not forced onto it)
+    const int tmax = sp.tm > 4 ? 8 : 4;
     const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes : var_ws_default(c));
     void* tabws;
     RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * (sizeof(Aff<F>) + sizeof(Jac<F>)), &tabws));
@@ -1817,6 +1830,17 @@ template <class C> struct Impl {
       for (const MillerTask& t : vp.mt)
         for (int q = 0; q < t.np; q++) pairs += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix / mc.var : 1.0;
       c->work_hint = (uint64_t)((double)N * pairs);
+    }
+    if (getenv("GS_PLAN_TRACE")) {
+      const MCost mc = mcost(c->curve, twin);
+      fprintf(stderr, "[plan] verify ty %d N %zu (fill %zu) m %d n %d: miller mode %d budget %.0f, %d tasks, lanes:", ty, N,
+              fillN(c, N), m, n, mode, budget, (int)ntask);
+      for (const MillerTask& t : vp.mt) {
+        double l = mc.base;
+        for (int q = 0; q < t.np; q++) l += pair_fixed(c->line_tables, t.pr[q]) ? mc.fix : mc.var;
+        fprintf(stderr, " %.0f", mode >= 2 ? pair_lane_cost(c, t) : l);
+      }
+      fprintf(stderr, "; waves %zu\n", ((mode >= 2 ? 2 : 1) * N * ntask + 63) / 64);
     }
     if (mode == 2)
       RC(launch_seg<k_miller_pair<C, false>>(c, "k_miller.pair", 2 * N * ntask, 64, 2 * N * ntask, ntask, dmt, parr, qarr,
@@ -2758,7 +2782,9 @@ int gs_verify_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, co
 // chip by itself and separate launches with per-part lane shapes are as fast (measured: profiles/r3/mixed_merge.txt).
 static bool merge_parts(const gs_ctx* c, size_t total_n) {
   if (c->mixed_merge >= 0) return c->mixed_merge != 0;
-  return total_n <= 32 * c->simd_slots;  // <= 2^15 equations on a 256-CU device
+  // <= 2^14 equations on a 256-CU device (profiles/r3/mixed_merge.txt: merged 103 against 112 ms in sequence at 2^14,
+  // 193 against 182 ms at 2^15, where every part fills the chip with its own lane shapes)
+  return total_n <= 16 * c->simd_slots;
 }
 extern "C++" {
 template <class FN> static int mixed_run(gs_ctx* c, int nparts, size_t total_n, FN part_fn) {

@@ -387,16 +387,37 @@ GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const A
   Line<C> l, lp;
   LineAcc<C> acc;
   int li = 0;
+  // The products of one round: the lane's own line at its own P, the partner's line at the lane's P for the partner's
+  // triple.  Both lanes of a pair sit in the same wave, so what the WAVE executes is the union of its lanes' branches.
+  // A full round is two products on every lane.  The last round of an ODD number of stepping triples has one line only:
+  // lane 0 owes its own line, lane 1 the partner's -- taken as two branches the wave would run two products of which
+  // each lane uses one (until round 3 it did: a lane of 1 stepping triple cost as much as one of 2, 9.2 ms instead of
+  // ~6.5 ms for the 20-task plans of small batches).  So: one product slot whose operands are selected per lane.
+  auto products = [&](const Line<C>& mine, int ko, int kp) {
+    const bool own_ok = ko < nstep && ((live >> ko) & 1), par_ok = kp < nstep && ((live >> kp) & 1);
+    xch.put(mine);
+    if (own_ok && par_ok) {
+      acc.add(f, mine, ps[ko]);
+      lp = xch.get();
+      acc.add(f, lp, ps[kp]);
+    } else {
+      lp = xch.get();
+      if (own_ok || par_ok) {
+        Line<C> use;  // (word-wise selects, not a branch per operand: a branch would bring the two products back)
+        use.l0 = select(own_ok, mine.l0, lp.l0);
+        use.lx = select(own_ok, mine.lx, lp.lx);
+        use.ly = select(own_ok, mine.ly, lp.ly);
+        acc.add(f, use, ps[own_ok ? ko : kp]);
+      }
+    }
+  };
   for (int i = C::LOOP_LEN - 2; i >= 0; i--) {
     acc.flush(f);
     f12_sqr(f, f);
     for (int r = 0; r < rounds; r++) {
       const int ko = 2 * r + a, kp = 2 * r + 1 - a;
       miller_dbl(ts[r], l);
-      xch.put(l);
-      if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
-      lp = xch.get();
-      if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
+      products(l, ko, kp);
     }
     for (int k = nstep; k < np; k++)
       if ((live >> k) & 1) acc.add(f, fixed[k][li], ps[k]);
@@ -408,10 +429,7 @@ GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const A
         Aff<Fp2<C>> q = qown[r];
         if (d < 0) q.y = neg(q.y);
         miller_add(ts[r], l, q);
-        xch.put(l);
-        if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
-        lp = xch.get();
-        if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
+        products(l, ko, kp);
       }
       for (int k = nstep; k < np; k++)
         if ((live >> k) & 1) acc.add(f, fixed[k][li], ps[k]);
@@ -432,10 +450,7 @@ GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const A
           qf.y = neg(mul(q.y, frob_coeff<C>(2, 3)));
         }
         miller_add(ts[r], l, qf);
-        xch.put(l);
-        if (ko < nstep && ((live >> ko) & 1)) acc.add(f, l, ps[ko]);
-        lp = xch.get();
-        if (kp < nstep && ((live >> kp) & 1)) acc.add(f, lp, ps[kp]);
+        products(l, ko, kp);
       }
       for (int k = nstep; k < np; k++)
         if ((live >> k) & 1) acc.add(f, fixed[k][li + e], ps[k]);
