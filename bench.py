@@ -411,15 +411,8 @@ class Bench:
         eng.sync()
         dt_d = (time.perf_counter() - t0) / steps
         assert okbuf.all() and wl.ok.cpu().numpy().all() and (o["pi"] == host(wl.pi)).all()
-        # the same arrays page-locked once (gs_host_register): DMA straight from / to them, no staging copy
-        regs = [X, Y, A, B, G, R, S, T, tgt, okbuf] + list(o.values())
-        for a in regs:
-            eng.host_register(a)
-        o["pi"][:] = 0
-        dt_p = host_rate()
-        assert okbuf.all() and (o["pi"] == host(wl.pi)).all()
-        for a in regs:
-            eng.host_unregister(a)
+        # (the same arrays page-locked once with gs_host_register -- DMA straight from / to them -- are measured by
+        # tools/host_path_rate.py, profiles/r3/host_path_rate.txt: 0.97 at 2^16; not repeated on every bench run)
         nbytes = sum(a.nbytes for a in (X, Y, A, B, G, R, S, T, tgt)) + sum(v.nbytes for v in o.values()) * 2 + \
             A.nbytes + B.nbytes + G.nbytes + N
         del wl
@@ -427,10 +420,8 @@ class Bench:
         return {"value": N / dt_h, "ms_per_step": dt_h * 1e3, "steps": steps,
                 "device_resident_value": N / dt_d, "device_resident_ms_per_step": dt_d * 1e3,
                 "ratio_to_device_resident": dt_d / dt_h, "pcie_bytes_per_step": int(nbytes),
-                "page_locked": {"value": N / dt_p, "ms_per_step": dt_p * 1e3, "ratio_to_device_resident": dt_d / dt_p},
                 "workload": "2^%d PPE m=%d n=%d BLS12-381 through gs_prove_batch + gs_verify_batch (pageable host arrays "
-                            "in, result arrays the caller keeps; pinned staging pipeline inside the library; "
-                            "page_locked: the same arrays registered once with gs_host_register)" % (log2n, m, n)}
+                            "in, result arrays the caller keeps; pinned staging pipeline inside the library)" % (log2n, m, n)}
 
     def describe(self, log2n, curve, ty, mixed, mode, m, n):
         return "2^%d independent %s equations per GPU, m=%d n=%d, %s, commit_and_prove+verify(%s)" % (

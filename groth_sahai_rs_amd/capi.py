@@ -155,6 +155,15 @@ class Engine:
     def sync(self):
         self._chk(self.lib.gs_sync(self.ctx))
 
+    @staticmethod
+    def host_buffer(nbytes):
+        """A uint8 array on a fresh anonymous mapping of its own (page-aligned, never part of the allocator's heap):
+        what to hand to host_register.  Heap memory is reused without being unmapped, and the runtime may still hold
+        its own pin of a freed buffer at the same addresses (include/gs_amd.h, gs_host_register)."""
+        import mmap
+
+        return np.frombuffer(mmap.mmap(-1, max(int(nbytes), 1)), dtype=np.uint8)[:nbytes]
+
     def host_register(self, arr):
         """Page-lock a numpy array the caller reuses across host-pointer calls (gs_host_register): the pipeline then
         moves it by DMA directly, without the staging copy."""

@@ -283,6 +283,8 @@ struct CopyPool {
   }
 };
 
+static std::mutex g_reg_mu;
+static std::map<const uint8_t*, size_t> g_reg;  // gs_host_register: start -> bytes
 struct HostPipe {
   struct Arr {
     const void* hin = nullptr;
@@ -293,21 +295,12 @@ struct HostPipe {
     bool enq = false;
     bool direct = false;  // the caller's array is page-locked already: DMA to / from it, no staging copy
   };
-  // Page-locked host memory (hipHostMalloc, hipHostRegister / gs_host_register, a torch pinned tensor) is recognised
-  // per array: both ends of the array must lie in it.
-  static bool host_pinned(const void* p, size_t bytes) {
-    static const bool off = getenv("GS_PIPE_NO_DIRECT") != nullptr;
-    if (off || !p || !bytes) return false;
-    for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + bytes - 1}) {
-      hipPointerAttribute_t at;
-      if (hipPointerGetAttributes(&at, q) != hipSuccess) {
-        (void)hipGetLastError();  // pageable memory: "invalid value" on some runtimes, "unregistered" on others
-        return false;
-      }
-      if (at.type != hipMemoryTypeHost) return false;
-    }
-    return true;
-  }
+  // Page-locked caller memory is what was registered through gs_host_register -- the library's own list, nothing else.
+  // (The first version asked the runtime, hipPointerGetAttributes on both ends of the array.  That also reports ranges
+  // the runtime itself has pinned behind the caller's back -- the source of an earlier pageable hipMemcpy, kept in its
+  // pin cache, possibly mapped READ-ONLY, possibly belonging to a buffer that has been freed since and whose addresses a
+  // new array now occupies.  A D2H straight into such a range ended in "write access to a read-only page" on the GPU.)
+  static bool host_pinned(const void* p, size_t bytes);
   gs_ctx* c;
   Arr arr[16];
   hipEvent_t ev1[16] = {nullptr}, ev2[16] = {nullptr};
@@ -489,6 +482,15 @@ struct HostPipe {
     return GS_OK;
   }
 };
+bool HostPipe::host_pinned(const void* p, size_t bytes) {
+  static const bool off = getenv("GS_PIPE_NO_DIRECT") != nullptr;
+  if (off || !p || !bytes) return false;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  auto it = g_reg.upper_bound((const uint8_t*)p);
+  if (it == g_reg.begin()) return false;
+  --it;  // the last registration that starts at or before p
+  return (const uint8_t*)p + bytes <= it->first + it->second;
+}
 static inline int need(gs_ctx* c, unsigned mask) { return c->pipe ? c->pipe->need(mask) : GS_OK; }
 static inline int out_ready(gs_ctx* c, unsigned mask) { return c->pipe ? c->pipe->out_ready(mask) : GS_OK; }
 // array slots of the host-pointer entry points
@@ -1757,7 +1759,11 @@ template <class C> struct Impl {
             }
           }
         }
-        if (mode == 2 && c->miller_twin != 2) mode = 3;  // planned: the DPP exchange (166.7 vs 170.0 ms at 2^16)
+        // planned exchange of the pair kernel: LDS slots on BLS12-381, DPP on BN254.  (DPP won until the round loop's
+        // products moved into one lambda, 166.7 vs 170.0 ms; with that shape the partner's line parked in LDS across
+        // the lane's own product beats the 84 registers it occupies: 147.6 vs 155.0 ms at 2^16, 41.3 vs 42.5 at 2^14,
+        // 12.7 vs 13.2 at 2^12; BN254's shorter lines keep DPP ahead by 0.6 %: profiles/r3/ab_exchange.txt)
+        if (mode == 2) mode = c->miller_twin == 3 ? 3 : c->miller_twin == 2 ? 2 : (c->curve == 0 ? 2 : 3);
         if (c->miller_choice.size() > 4096) c->miller_choice.clear();
         c->miller_choice[key] = std::make_pair(mode, budget);
       }
@@ -2496,29 +2502,27 @@ const char* gs_last_error(gs_ctx* c) { return c ? c->err.c_str() : "null context
 // Page-lock a caller's buffer (a Vec the Rust side reuses from call to call): the host-pointer entry points then move
 // it by DMA directly instead of through the staging copy.  The runtime counts registrations of a range silently; the
 // library keeps its own list so that a second registration, or the release of an unknown pointer, is an error.
-static std::mutex g_reg_mu;
-static std::map<void*, size_t> g_reg;
 int gs_host_register(gs_ctx* c, void* ptr, size_t bytes) {
   RC(check_ctx(c, false));
   if (!ptr || !bytes) return GS_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_reg_mu);
-  if (g_reg.count(ptr)) return fail(c, GS_ERR_ARG, "gs_host_register: already registered");
+  if (g_reg.count((const uint8_t*)ptr)) return fail(c, GS_ERR_ARG, "gs_host_register: already registered");
   hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return fail(c, e == hipErrorOutOfMemory ? GS_ERR_ALLOC : GS_ERR_ARG, "hipHostRegister", e);
   }
-  g_reg[ptr] = bytes;
+  g_reg[(const uint8_t*)ptr] = bytes;
   return GS_OK;
 }
 int gs_host_unregister(gs_ctx* c, void* ptr) {
   RC(check_ctx(c, false));
   if (!ptr) return GS_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_reg_mu);
-  if (!g_reg.count(ptr)) return fail(c, GS_ERR_ARG, "gs_host_unregister: not registered here");
+  if (!g_reg.count((const uint8_t*)ptr)) return fail(c, GS_ERR_ARG, "gs_host_unregister: not registered here");
   HIPCHK(c, hipStreamSynchronize(c->stream));  // nothing of this context may still be moving the buffer
   hipError_t e = hipHostUnregister(ptr);
-  g_reg.erase(ptr);
+  g_reg.erase((const uint8_t*)ptr);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return fail(c, GS_ERR_ARG, "hipHostUnregister", e);

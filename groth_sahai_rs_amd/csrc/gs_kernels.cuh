@@ -754,7 +754,10 @@ struct k_miller {
 //    21 + 21 instructions for BLS12-381); the block is ONE wave, so program order is LDS order and the barriers below
 //    are compiler fences; the partner's line is fetched only after the lane's own line product;
 //  * PairDpp: one v_mov_b32 with quad_perm [1,0,3,2] per dword at put(), no memory at all.
-// Measured at 2^16 (one box, alternating): DPP 157.1-158.9 ms, LDS 161.3-161.6 ms -- the planner takes DPP.
+// Measured at 2^16 (one box, alternating).  First shape of the round loop: DPP 157.1-158.9 ms, LDS 161.3-161.6 ms.
+// Final shape (the products of a round in one lambda, gs_pairing.cuh): LDS **147.5-147.7 ms**, DPP 154.6-156.0 ms on
+// BLS12-381 (a line parked in LDS frees 84 registers across the lane's own product); BN254 100.5 (DPP) against
+// 101.3 ms (LDS).  The planner takes LDS on BLS12-381 and DPP on BN254 (profiles/r3/ab_exchange.txt).
 template <class C> GS_HD int32_t& line_word(Line<C>& l, int i) {
   constexpr int L = C::L;
   const int c = i / L, j = i % L;

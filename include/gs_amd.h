@@ -94,13 +94,15 @@ int gs_set_option(gs_ctx* ctx, const char* key, int value);
 int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the context's stream */
 /* Page-locked caller memory.  The host-pointer entry points below (gs_prove_batch, gs_verify_batch, the mixed and the
  * Statement calls, gs_multi_*) stage pageable arrays through a pinned buffer of their own (one memcpy per array and
- * direction on worker threads).  An array that already lies in page-locked memory -- hipHostMalloc, hipHostRegister,
- * or a buffer registered here -- is recognised per array (both of its ends are looked up) and moved by DMA straight
- * from / to the caller's memory: no staging copy, uploads start at once, and the call reaches the device-resident
- * rate within 1-2 % (profiles/r3/host_path_rate.txt).  A Rust caller registers the Vecs it reuses across calls once
- * (registration costs about as much as copying the buffer a few times).  [prove.rs:29-52 / verifier.rs:18-21 take
- * slices; this is the cheap way to hand them over]
- * gs_host_unregister waits for the context's stream first.  GS_ERR_ARG: null / empty / already registered / unknown. */
+ * direction on worker threads).  An array that lies inside a range registered HERE is moved by DMA straight from / to
+ * the caller's memory: no staging copy, uploads start at once (profiles/r3/host_path_rate.txt).  A Rust caller
+ * registers the Vecs it reuses across calls once (registration costs about as much as copying the buffer a few times).
+ * [prove.rs:29-52 / verifier.rs:18-21 take slices; this is the cheap way to hand them over]
+ * Only ranges registered through this call count: memory page-locked by other means (hipHostMalloc, another library's
+ * hipHostRegister) is staged like pageable memory -- the runtime cannot tell such memory from ranges it has pinned
+ * itself for an earlier pageable copy, and those may be mapped read-only or belong to a buffer freed since.
+ * gs_host_unregister waits for the context's stream first.  GS_ERR_ARG: null / empty / already registered (here or
+ * elsewhere) / unknown. */
 int gs_host_register(gs_ctx* ctx, void* ptr, size_t bytes);
 int gs_host_unregister(gs_ctx* ctx, void* ptr);
 const char* gs_last_error(gs_ctx* ctx);
