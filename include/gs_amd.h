@@ -72,7 +72,7 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
 /* Planner overrides (results never change, only which kernel shapes run; tests force every shape through them):
  *   "miller_twin"  -1 planned | 0 one accumulator per Miller lane | 1 two (lines of Q shared by both G1 partners)
  *                   | 2 the same triples on a PAIR of lanes, one accumulator each, lines exchanged through LDS | 3 the
- *                   same with a DPP exchange
+ *                   same with a DPP exchange (planned: the pair form, LDS on BLS12-381, DPP on BN254)
  *   "miller_ch"     0 planned | 1..12 pairs (triples) per Miller lane
  *   "var_tm"        0 planned | 1..8 variable-base terms per Straus lane
  *   "var_mo"        0 planned | 1, 2, 4 outputs over the same bases served by one lane's table build
@@ -85,11 +85,15 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream
  *   "var_tab"      -1 planned | 0 the verifier's Gamma^T c on Straus lanes with their own tables | 1 on window tables of
  *                   the commitment components shared by all outputs (8-bit windows; what large arities use)
- *   "mixed_merge"  -1 planned | 0 the parts of a mixed call run one after the other | 1 their launches are merged
+ *   "mixed_merge"  -1 planned (merged up to 2^14 equations per call on a 256-CU device) | 0 the parts of a mixed call run
+ *                   one after the other | 1 their launches are merged
  * The same knobs are read ONCE at gs_ctx_create from the environment for experiments without recompiling the caller:
  * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_VAR_MO, GS_VAR_W, GS_RED_K, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP (same values).
  * Unset = planned.  GS_COPY_THREADS (default 4): memcpy workers of the host-pointer entry points; GS_ROCTX=1: load the
- * roctx library for phase markers ("gs.prove", "gs.prove.g1", "gs.verify.miller" ...) even when no profiler mapped it. */
+ * roctx library for phase markers ("gs.prove", "gs.prove.g1", "gs.verify.miller" ...) even when no profiler mapped it.
+ * Diagnostics on stderr: GS_PLAN_TRACE=1 (the verifier's Miller plan per call: mode, budget, tasks per equation, planned
+ * cost of each task's lane, waves), GS_PIPE_TRACE=1 (time line of a host-pointer call's staging, uploads and arrivals);
+ * GS_PIPE_NO_DIRECT=1 stages registered arrays like pageable ones. */
 int gs_set_option(gs_ctx* ctx, const char* key, int value);
 int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the context's stream */
 /* Page-locked caller memory.  The host-pointer entry points below (gs_prove_batch, gs_verify_batch, the mixed and the
