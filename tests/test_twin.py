@@ -226,14 +226,15 @@ def test_endomorphism_scalar_multiplication_random(twin, cname):
 @pytest.mark.parametrize("cname", CURVES)
 def test_fixed_argument_line_tables(twin, cname):
     """Pairs whose G2 argument is tabulated (miller_line_table) give the same pairing product as stepping the twist
-    point, in the single and the twin Miller loop, for every subset of tabulated pairs."""
+    point, in the single, the twin and the lane-pair Miller loop (the latter as two host threads with the device's put / get
+    exchange discipline), for subsets of tabulated pairs that leave odd and even numbers of stepping triples."""
     c = curve(cname)
     ps = c.golden["pairing_sum"]
     P = np.concatenate([c.g1(x[1]) for x in ps["x"]])
     Q = np.concatenate([c.g2(y[1]) for y in ps["y"]])
     n = len(ps["x"])
     f = getattr(twin, "twin_multi_pairing_fixed_" + cname)
-    for twin_mode in (0, 1):
+    for twin_mode in (0, 1, 2):  # single accumulator, twin lane, lane pair (two host threads, multi_miller_pair)
         outs = []
         for mask in (0, 1, (1 << n) - 1, 0b1010 & ((1 << n) - 1)):
             out = np.zeros(2 * 12 * c.nq, dtype=np.uint64)
@@ -242,3 +243,13 @@ def test_fixed_argument_line_tables(twin, cname):
         assert c.f12_dec(outs[0][:12 * c.nq]) == ps["out"][3]  # cell (1, 1) of the fixture
         for o in outs[1:]:
             assert (o == outs[0]).all()
+        if twin_mode:  # both accumulators were given the same G1 arguments
+            assert (outs[0][12 * c.nq:] == outs[0][:12 * c.nq]).all()
+    # longer lists (the fixture's pairs three times over: odd and even numbers of stepping triples, up to three rounds of
+    # the lane pair, with and without tabulated pairs behind them): the lane pair equals the twin lane
+    P3, Q3, n3 = np.tile(P, 3), np.tile(Q, 3), 3 * n
+    for mask in (0, 1, 0b11 << (n3 - 2), (1 << n3) - 2):
+        a, b = np.zeros(2 * 12 * c.nq, dtype=np.uint64), np.zeros(2 * 12 * c.nq, dtype=np.uint64)
+        f(n3, ptr(P3), ptr(Q3), mask, ptr(a), 1)
+        f(n3, ptr(P3), ptr(Q3), mask, ptr(b), 2)
+        assert (a == b).all(), mask

@@ -5,9 +5,11 @@
 // contract and every lazy add/sub asserts that int32 limbs would not overflow.
 // Test infrastructure only -- never loaded by the product.
 #include <string.h>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <vector>
 #include "../../groth_sahai_rs_amd/csrc/gs_params_bls12_381.h"
 #include "../../groth_sahai_rs_amd/csrc/gs_params_bn254.h"
 #include "../../groth_sahai_rs_amd/csrc/gs_pairing.cuh"
@@ -377,7 +379,63 @@ template <class C> struct Twin {
       }
     }
     Fp12<C> f, f1, e;
-    if (twin_mode) {
+    if (twin_mode == 2) {
+      // the lane-PAIR form of the twin loop (multi_miller_pair): two host threads stand for lanes 2i and 2i + 1, each
+      // with one accumulator, the stepping triples dealt out alternately; lines cross through a two-slot exchange
+      // with the same put / get discipline as the device's LDS slots.  Stepping triples come first, as the planner
+      // orders a task's list.
+      std::vector<int> ord;
+      for (int i = 0; i < np; i++)
+        if (!((mask >> i) & 1)) ord.push_back(i);
+      const int nstep = (int)ord.size();
+      for (int i = 0; i < np; i++)
+        if ((mask >> i) & 1) ord.push_back(i);
+      std::vector<Aff<F1>> Pp(np);
+      std::vector<const Line<C>*> fxp(np);
+      std::vector<Aff<F2>> qo[2];
+      uint32_t qok = 0;
+      for (int k = 0; k < np; k++) {
+        Pp[k] = P[ord[k]];
+        fxp[k] = fx[ord[k]];
+        if (!aff_is_inf(Q[ord[k]])) qok |= 1u << k;
+        if (k < nstep) qo[k & 1].push_back(Q[ord[k]]);
+      }
+      for (int a = 0; a < 2; a++) qo[a].resize((nstep + 1) / 2 + 1);
+      struct Exchange {
+        Line<C> slot[2];
+        std::atomic<int> arrived{0}, phase{0};
+        void barrier() {
+          int ph = phase.load();
+          if (arrived.fetch_add(1) == 1) {
+            arrived.store(0);
+            phase.store(ph + 1);
+          } else {
+            while (phase.load() == ph) std::this_thread::yield();
+          }
+        }
+      } ex;
+      struct Lane {
+        Exchange* ex;
+        int lane;
+        void put(const Line<C>& m) {
+          ex->barrier();  // the partner has taken the previous line
+          ex->slot[lane] = m;
+          ex->barrier();
+        }
+        Line<C> get() const { return ex->slot[lane ^ 1]; }
+      };
+      Fp12<C> acc[2];
+      std::thread th[2];
+      for (int a = 0; a < 2; a++)
+        th[a] = std::thread([&, a] {
+          Lane x{&ex, a};
+          std::vector<Proj2<C>> ts((nstep + 1) / 2 + 1);
+          multi_miller_pair(acc[a], a, Pp.data(), qo[a].data(), qok, nstep, np, ts.data(), fxp.data(), x);
+        });
+      for (int a = 0; a < 2; a++) th[a].join();
+      f = acc[0];
+      f1 = acc[1];
+    } else if (twin_mode) {
       uint8_t* live = new uint8_t[np];
       multi_miller2(f, f1, P, P, Q, np, T, live, fx);
       delete[] live;
