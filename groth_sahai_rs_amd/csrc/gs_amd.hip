@@ -1071,6 +1071,12 @@ static void share_tables(const gs_ctx* c, size_t N, SidePlan& sp, bool g2) {
   }
   sp.mo = best_mo;
   sp.w = best_w;
+  if (getenv("GS_PLAN_TRACE")) {
+    size_t lanes = 0;
+    for (auto& f : fam) lanes += (f.size() + best_mo - 1) / best_mo;
+    fprintf(stderr, "[plan] straus %s fill %zu: %zu groups in %zu families (largest %zu), <= %d terms; outputs per build %d, window %d, "
+            "%zu lanes per equation\n", g2 ? "G2" : "G1", N, sp.grp.size(), fam.size(), share, ntmax, best_mo, best_w, lanes);
+  }
   if (best_mo == 1) return;
   std::vector<GrpTask> merged;
   for (const std::vector<size_t>& f : fam) {
