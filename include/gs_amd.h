@@ -105,7 +105,8 @@ int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the
  * Only ranges registered through this call count: memory page-locked by other means (hipHostMalloc, another library's
  * hipHostRegister) is staged like pageable memory -- the runtime cannot tell such memory from ranges it has pinned
  * itself for an earlier pageable copy, and those may be mapped read-only or belong to a buffer freed since.
- * gs_host_unregister waits for the context's stream first.  GS_ERR_ARG: null / empty / already registered (here or
+ * Registrations are per process, not per context: they outlive gs_ctx_destroy and end with gs_host_unregister (any live
+ * context may be passed).  gs_host_unregister waits for the context's stream first.  GS_ERR_ARG: null / empty / already registered (here or
  * elsewhere) / unknown. */
 int gs_host_register(gs_ctx* ctx, void* ptr, size_t bytes);
 int gs_host_unregister(gs_ctx* ctx, void* ptr);
