@@ -266,7 +266,10 @@ struct CopyPool {
   }
   // copy [src, src + n) to dst in pieces; *left counts the pieces still to do
   void submit(void* dst, const void* src, size_t n, std::atomic<int>* left) {
-    const size_t piece = (size_t)2 << 20;
+    // 2 MB pieces for large arrays; a mid-size array (the 1.5-6 MB arrays of a 2^12 batch) is cut finer so that every
+    // worker gets a share of it
+    size_t piece = n / (2 * th.size() + 1);
+    piece = std::min(std::max(piece, (size_t)256 << 10), (size_t)2 << 20) & ~(size_t)4095;
     size_t np = (n + piece - 1) / piece;
     left->fetch_add((int)np, std::memory_order_relaxed);
     {
