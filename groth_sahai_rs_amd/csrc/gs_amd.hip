@@ -371,7 +371,11 @@ struct HostPipe {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (hipStream_t* st : {&c->copy_stream, &c->copy_stream2, &c->copy_out_stream, &c->copy_out_stream2})
-      if (!*st) HIPCHK(c, hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest));
+      if (!*st && hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+        (void)hipGetLastError();  // no priority levels here: an ordinary stream (correct, possibly serialized as above)
+        *st = nullptr;
+        HIPCHK(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+      }
     if (!c->pev_ready) HIPCHK(c, hipEventCreateWithFlags(&c->pev_ready, hipEventDisableTiming));
     if (!c->pool) {
       int nt = 4;
