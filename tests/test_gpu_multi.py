@@ -168,3 +168,43 @@ def test_multi_rlc_rejects_null_rho():
                                           ctypes.c_void_p(0), ctypes.c_void_p(0), p(ok))
     assert rc == 3 and "rho" in me.lib.gs_multi_last_error(me.h).decode()
     me.close()
+
+
+def test_multi_shards_read_sub_ranges_of_registered_arrays():
+    """The host entry points of the multi layer hand every shard a SUB-RANGE of the caller's arrays.  With the arrays
+    page-locked through gs_host_register (a per-process list: any context may register), every shard's uploads go by
+    DMA straight out of its sub-range -- the look-up is by containment, on the shards' own threads at once.  Same bytes
+    and verdicts as the single-device engine."""
+    import groth_sahai_rs_amd as gs
+    from groth_sahai_rs_amd.workload import Workload
+
+    N, m, n, ty = 203, 3, 4, 0
+    eng = gs.Engine(0, 0)
+    wl = Workload(eng, ty=ty, N=N, m=m, n=n, seed=8891, corrupt_every=0)
+    wl.prove()
+    eng.sync()
+    host = lambda t: t.cpu().numpy()
+
+    def fresh(a):
+        b = eng.host_buffer(a.nbytes)
+        b[:] = a.reshape(-1).view(np.uint8)
+        return b
+
+    X, Y, A, B, G, R, S, T, tgt = [fresh(host(getattr(wl, k))) for k in ("X", "Y", "A", "B", "Gamma", "R", "S", "T", "target")]
+    want = {k: host(getattr(wl, k)) for k in ("xcoms", "ycoms", "pi", "theta")}
+    regs = [X, Y, A, B, G, R, S, T, tgt]
+    for a in regs:
+        eng.host_register(a)
+    me = gs.MultiEngine(0, [0, 0, 0], shared_devices=True)
+    me.set_crs(wl.crs)
+    got = me.prove_batch(ty, N, m, n, X, Y, A, B, G, R, S, T)
+    for k in want:
+        assert (got[k] == want[k]).all(), k
+    bad = got["theta"].copy()
+    bad[(N - 1) * (bad.size // N) + 7] ^= 16  # last shard
+    ok = me.verify_batch(ty, N, m, n, A, B, G, tgt, got["xcoms"], got["ycoms"], got["pi"], bad)
+    assert ok[:-1].all() and ok[-1] == 0
+    me.close()
+    for a in regs:
+        eng.host_unregister(a)
+    eng.close()
