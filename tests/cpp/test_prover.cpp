@@ -6,6 +6,7 @@
 //   + wire-format expectations from oracle/gs_wire_oracle.py: Commit1 (compressed), EquProof (compressed),
 //     the equation (uncompressed), the CRS (compressed)
 // Exit code 0 and "OK <checks>" on success.
+#include <sys/mman.h>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -182,12 +183,16 @@ static void run(const CRS& crs, uint32_t m, uint32_t n, const Bytes& X, const By
 
   // page-locked caller memory: the region registers and releases; registering it twice, or releasing it twice, is refused
   {
-    Bytes buf(1 << 16, 0);
+    // (a mapping of its own, not allocator heap: include/gs_amd.h, gs_host_register)
+    const size_t len = 1 << 16;
+    void* buf = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    CHECK(buf != MAP_FAILED);
     {
-      PinnedRegion pr(*crs.ctx, buf.data(), buf.size());
-      CHECK(gs_host_register(crs.ctx->c, buf.data(), buf.size()) != GS_OK);
+      PinnedRegion pr(*crs.ctx, buf, len);
+      CHECK(gs_host_register(crs.ctx->c, buf, len) != GS_OK);
     }
-    CHECK(gs_host_unregister(crs.ctx->c, buf.data()) != GS_OK);
+    CHECK(gs_host_unregister(crs.ctx->c, buf) != GS_OK);
+    munmap(buf, len);
   }
 
   // the several-GPU entry (gs_ctx_create_multi; one device on this box): a batch of three proofs of the same
