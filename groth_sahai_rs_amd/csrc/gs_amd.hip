@@ -1196,7 +1196,9 @@ template <class C, class F> static int run_red(gs_ctx* c, size_t N, const RedLau
   c->work_hint = N * (uint64_t)nslots;  // partial sums folded
   // outputs per lane (one inversion each lane): as many as still leave the launch a full round of waves
   int K = 1;
-  while (K < RED_K && K * 2 <= (int)r.nred && (fillN(c, N) * ((r.nred + 2 * K - 1) / (2 * K)) + 63) / 64 >= c->simd_slots) K *= 2;
+  // (K may exceed the outputs of an equation: 6 outputs go to ONE lane of 8 rather than to lanes of 4 + 2 with an
+  // inversion each, once a lane per equation still fills the chip)
+  while (K < RED_K && K < (int)r.nred && (fillN(c, N) * ((r.nred + 2 * K - 1) / (2 * K)) + 63) / 64 >= c->simd_slots) K *= 2;
   if (c->red_k > 0) K = std::min(c->red_k, RED_K);
   size_t lanes = N * ((r.nred + K - 1) / K);
   return launch_seg<k_red<C, F>>(c, r.name.c_str(), lanes, 64, lanes, (int)r.nred, dred, part, nslots, r.outs, K);
@@ -2491,7 +2493,8 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
     if (value < 0 || (value > 0 && value < 64) || value % 64) return fail(c, GS_ERR_ARG, "var_ws_lanes: 0 or a multiple of 64");
     c->var_ws_lanes = value;
   } else if (k == "red_k") {
-    if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_ARG, "red_k: 0 (planned), 1, 2, 4");
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+      return fail(c, GS_ERR_ARG, "red_k: 0 (planned), 1, 2, 4, 8");
     c->red_k = value;
   } else if (k == "coop_fe") {
     if (value < 0 || value > 2) return fail(c, GS_ERR_ARG, "coop_fe: 0 never, 1 planned, 2 always");

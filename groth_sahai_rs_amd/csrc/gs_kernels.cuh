@@ -624,7 +624,7 @@ struct k_fix {
 
 // One lane = up to RED_K consecutive outputs (two points each) and ONE inversion for all of them (Montgomery's trick
 // over their Z coordinates): the inversion is most of this kernel (496 of ~530 Fq multiplications per output in G1).
-constexpr int RED_K = 4;
+constexpr int RED_K = 8;
 template <class C, class F>
 struct k_red {
   static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const RedTask* tasks, const Jac<F>* part,

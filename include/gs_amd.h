@@ -79,7 +79,7 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "var_w"         0 planned | 4, 5 window width of the Straus lanes (8 or 16 table entries per base)
  *   "var_ws_lanes"  0 = 2^19 | multiple of 64: Straus lanes per launch; bounds their table workspace (3.5 .. 28 KB
  *                   of device memory per lane), larger batches run as several launches over it
- *   "red_k"         0 planned | 1, 2, 4 outputs per reduction lane (one inversion per lane)
+ *   "red_k"         0 planned | 1, 2, 4, 8 outputs per reduction lane (one inversion per lane)
  *   "coop_fe"       0 one lane per final exponentiation | 1 planned | 2 always the 3-lane cooperative form
  *   "line_tables"   1 CRS G2 arguments read precomputed Miller lines | 0 they are stepped like any other point
  *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream

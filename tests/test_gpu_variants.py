@@ -1,7 +1,7 @@
 """Every kernel SHAPE the planner can pick is compared with the C oracle.
 
 The planner (csrc/gs_amd.hip: miller_cost, pick_tm, coop_fe) switches kernels with the batch size: twin-accumulator
-Miller lanes, 1..12 pairs per lane, Straus groups of 4 / 8 terms (one to four outputs per table build, 4- or 5-bit windows), one, two or four outputs per inversion in the reductions, one-lane or 3-lane final exponentiation, table-reading
+Miller lanes, 1..12 pairs per lane, Straus groups of 4 / 8 terms (one to four outputs per table build, 4- or 5-bit windows), one, two, four or eight outputs per inversion in the reductions, one-lane or 3-lane final exponentiation, table-reading
 or stepping CRS pairs, side streams.  At the small N the oracle can follow, the planner alone would only ever choose
 the small-batch shapes; here every shape is FORCED through gs_set_option, all four equation types, both curves, every
 equation of the batch bit-exact (commitments, pi, theta) and verdict-exact against oracle/gs_ref.c, and the library's
@@ -40,7 +40,8 @@ SHAPES = {
                                        line_tables=1, overlap=1),
     # the verifier's Gamma^T c on window tables of the commitment components shared by all outputs (what large arities
     # use; forced here at 4 x 4): k_tab_build + k_var_tab8
-    "pair12_tab8_lane": dict(red_k=2, miller_twin=3, miller_ch=12, var_tm=8, var_mo=2, var_w=5, coop_fe=0, line_tables=1,
+    # (red_k=8: every output of a side behind one inversion)
+    "pair12_tab8_lane": dict(red_k=8, miller_twin=3, miller_ch=12, var_tm=8, var_mo=2, var_w=5, coop_fe=0, line_tables=1,
                              overlap=0, var_tab=1),
 }
 MILLER_KERNEL = {0: "k_miller", 1: "k_miller.twin", 2: "k_miller.pair", 3: "k_miller.pairdpp"}
