@@ -7,9 +7,12 @@ pairing-product-equation batch (BASELINE.json metric).
               MI355X, commit_and_prove + exact verify; the other single-GPU configurations of BASELINE.json
               (configs[1] 2^12 PPE, configs[2] 2^16 mixed + batched verifier, configs[4] BN254 2^16) are measured
               after it and reported under "also" on the same JSON line.
-      N > 1 : configs[3], the 2^18-equation batch sharded over the N GPUs by contiguous equation blocks
-              (2^18 / N per GPU: 2^15 at N = 8).  No data-path collective for prove / exact verify; the ranks'
-              failure counts are combined with one RCCL all-reduce INSIDE the timed step (the rank-combined verdict).
+      N > 1 : the SAME per-GPU batch as N = 1 (2^16 equations per GPU, "scaling": "weak"): equations sharded over the
+              N GPUs by contiguous equation blocks, so that the driver's N = 1, 2, 4, 8 points are one curve (rounds
+              1-3 ran 2^18 / N per GPU and called it "strong" while the N = 1 point was a different total: VERDICT r3).
+              configs[3] itself (2^18 in all: 2^15 per GPU at N = 8) is `--gpus 8 --log2n 15`.  No data-path collective
+              for prove / exact verify; the ranks' failure counts are combined with one RCCL all-reduce INSIDE the
+              timed step (the rank-combined verdict).
               Launched without torchrun, this script starts its own N ranks (torch.distributed.run as a child
               process, before anything here touches the GPU) and forwards rank 0's JSON line.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's own launch line)
@@ -123,12 +126,22 @@ def cpu_latency_split(ref, reps=3):
                             "unsatisfied target: same work, verdict irrelevant)" % reps}
 
 
-# measured v_mad_u64_u32 issue peak of the chip (tools/ubench.hip, profiles/r1/ubench_valu.txt: 4.34 cycles per
-# wave-instruction per SIMD at the 2.4 GHz the runtime reports, 1024 SIMDs x 64 lanes) in G lane-mads/s
-VALU_MAD_PEAK_G = 1024 * 64 * 2.4e9 / 4.34 / 1e9
-# the same pipe at the clock these kernels actually run at (2.07 GHz under this load: profiles/r1/ubench_valu.txt,
-# DESIGN.md 4.1): what "executed_mad_frac" is priced against
-VALU_MAD_PEAK_AT_CLOCK_G = 1024 * 64 * 2.07e9 / 4.34 / 1e9
+# The multiply-add pipe, from ONE measurement (tools/ubench.hip, profiles/r4/ubench_valu.txt): with the
+# SIMDs saturated (8 waves each) a v_mad_u64_u32 / v_mad_i64_i32 wave-instruction takes 4.24 cycles of the nominal
+# 2.4 GHz of wall time while THAT kernel's own stamps (s_memtime / s_memrealtime) read 2.383 GHz: 4.21 real shader cycles
+# per wave-instruction per SIMD (a quarter-rate instruction on a 16-lane SIMD plus ~5 % issue overhead).
+MAD_CYCLES = 4.24 * 2.383 / 2.4
+SIMDS = 1024  # 256 CUs x 4
+NOMINAL_GHZ = 2.4
+
+
+def mad_peak_g(clock_ghz):
+    """measured multiply-add issue peak in G lane-mads/s at a given shader clock"""
+    return SIMDS * 64 * clock_ghz / MAD_CYCLES
+
+
+# at the nominal clock (what "frac" was priced against in rounds 1-3: kept for continuity of the series)
+VALU_MAD_PEAK_G = mad_peak_g(NOMINAL_GHZ)
 
 
 def latest_profile(name):
@@ -138,7 +151,7 @@ def latest_profile(name):
     return hits[-1] if hits else None
 
 
-def alu_roofline(work, ms, curve_id, dominant):
+def alu_roofline(work, ms, curve_id, dominant, clocks=None):
     """Useful Fq multiplications of one profiled step (per-kernel work items from gs_prof_get_work x the
     per-primitive counts of profiles/r*/fq_mul_counts.json, tools/count_fq_muls.py) x 2 L^2 multiply-adds each,
     against the measured v_mad_u64_u32 peak: SURVEY.md 8(d)'s ALU roofline.  Kernels without an entry (scalar
@@ -189,19 +202,35 @@ def alu_roofline(work, ms, curve_id, dominant):
     total = sum(muls.values())
     step_s = sum(ms.values()) / 1e3
     mads = cnt["mads_per_fq_mul"]
+    # The clock each kernel ran at, stamped INSIDE the very launches that were timed (gs_prof_get_clock: every wave of
+    # a segmented launch reads s_memtime / s_memrealtime around its body).  The step's clock is the time-weighted mean
+    # over the kernels that carry stamps; the peak is the measured multiply-add issue rate at THAT clock.  No second,
+    # separately measured clock enters (rounds 2-3 scaled a wall-clock peak by 2.07 / 2.4 once more: VERDICT r3 weak 4).
+    clocks = {k: v for k, v in (clocks or {}).items() if v and ms.get(k)}
+    wsum = sum(ms[k] for k in clocks)
+    step_clock = (sum(ms[k] * clocks[k] for k in clocks) / wsum) if wsum else NOMINAL_GHZ
+    dom_clock = clocks.get(dominant, step_clock)
+    peak = mad_peak_g(step_clock)
     dom = {}
     if dominant in muls and ms.get(dominant):
         a = muls[dominant] * mads / (ms[dominant] / 1e3) / 1e9
-        dom = {"kernel": dominant, "achieved": a, "frac": a / VALU_MAD_PEAK_G}
+        dom = {"kernel": dominant, "achieved": a, "clock_ghz": dom_clock, "peak": mad_peak_g(dom_clock),
+               "frac": a / mad_peak_g(dom_clock)}
     a = total * mads / step_s / 1e9
-    out = {"bound": "valu (v_mad_u64_u32 issue)", "achieved": a, "peak": VALU_MAD_PEAK_G, "unit": "G mad/s",
-           "frac": a / VALU_MAD_PEAK_G, "fq_muls_per_step": total, "mads_per_fq_mul": mads, "dominant": dom,
+    out = {"bound": "valu (v_mad_u64_u32 issue)", "achieved": a, "peak": peak, "unit": "G mad/s",
+           "frac": a / peak, "clock_ghz": step_clock,
+           "clock_source": ("s_memtime / s_memrealtime stamps of the profiled launches (gs_prof_get_clock), "
+                            "time-weighted over %d kernels" % len(clocks)) if clocks else "nominal (no stamps)",
+           "mad_cycles_per_wave_instruction": MAD_CYCLES, "peak_at_nominal_2p4ghz": VALU_MAD_PEAK_G,
+           "frac_at_nominal_2p4ghz": a / VALU_MAD_PEAK_G,
+           "clock_ghz_by_kernel": {k: round(v, 4) for k, v in clocks.items()},
+           "fq_muls_per_step": total, "mads_per_fq_mul": mads, "dominant": dom,
            "fq_muls_by_kernel": {k: round(v) for k, v in muls.items()}}
     # ---- the stricter readings.  `frac` above credits every Fq multiplication with the 2 L^2
     # multiply-adds of the radix-2^28 product at the nominal 2.4 GHz.
     #   executed_mad_frac      multiply-add instructions the kernels EXECUTE for this work (static counts of the
     #                          generated multiplier kernels x calls, from the CPU twin's second counter: a squaring is
-    #                          L (L + 1) / 2 + L^2, not 2 L^2) against the same pipe at the clock the kernels run at
+    #                          L (L + 1) / 2 + L^2, not 2 L^2) against the same peak (at the kernels' own clock)
     #   min_mads_per_fq_mul    what a saturated 32-bit-limb product would need (12 x 12 x 2 = 288 for BLS12-381):
     #                          frac_vs_min_mads prices the USEFUL arithmetic at that floor, at the measured clock
     ex = cnt.get("executed_mads")
@@ -209,15 +238,13 @@ def alu_roofline(work, ms, curve_id, dominant):
         emads = per_kernel(ex)
         etot = sum(emads.values())
         out["executed_mads_per_step"] = etot
-        out["peak_at_measured_clock"] = VALU_MAD_PEAK_AT_CLOCK_G
-        out["measured_clock_ghz"] = 2.07
-        out["executed_mad_frac"] = etot / step_s / 1e9 / VALU_MAD_PEAK_AT_CLOCK_G
+        out["executed_mad_frac"] = etot / step_s / 1e9 / peak
         if dominant in emads and ms.get(dominant):
-            out["dominant"]["executed_mad_frac"] = emads[dominant] / (ms[dominant] / 1e3) / 1e9 / VALU_MAD_PEAK_AT_CLOCK_G
+            out["dominant"]["executed_mad_frac"] = emads[dominant] / (ms[dominant] / 1e3) / 1e9 / mad_peak_g(dom_clock)
     mn = cnt.get("min_mads_per_fq_mul")
     if mn:
         out["min_mads_per_fq_mul"] = mn
-        out["frac_vs_min_mads"] = total * mn / step_s / 1e9 / VALU_MAD_PEAK_AT_CLOCK_G
+        out["frac_vs_min_mads"] = total * mn / step_s / 1e9 / peak
     return out
 
 
@@ -247,6 +274,18 @@ def pmc_traffic(tag, kernel_name):
         if base + "<" in k and ("true" in k) == flag:
             return v.get("hbm_bytes_per_launch_corrected"), os.path.relpath(p, ROOT)
     return None, None
+
+
+def distinct_devices(dist, local, world, coll_dev):
+    """number of distinct GPUs under the ranks of this job (ranks of one node: the set of their device ordinals)"""
+    if dist is None:
+        return 1
+    import torch
+
+    t = torch.zeros(world, dtype=torch.int64, device=coll_dev)
+    t[dist.get_rank()] = torch.cuda.current_device() + 1
+    dist.all_reduce(t)
+    return len(set(int(x) for x in t.tolist() if x))
 
 
 def self_spawn(args):
@@ -294,13 +333,16 @@ class Bench:
         eng = self.engine(curve)
         N = 1 << log2n
         rank, world, dist = self.rank, self.world, self.dist
+        ce = lambda k: min(1024, max(k // 4, 1))  # every batch carries corrupted proofs for the verdict checks
         if mixed:  # one CRS, three sub-batches of different types, proved and verified by ONE mixed call each
-            wls = [Workload(eng, ty=0, N=N // 2, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev)]
+            wls = [Workload(eng, ty=0, N=N // 2, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev, corrupt_every=ce(N // 2))]
             for t in (1, 2):
-                wls.append(Workload(eng, ty=t, N=N // 4, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev))
+                wls.append(Workload(eng, ty=t, N=N // 4, m=m, n=n, seed=20241220 + 2 + rank, device=self.dev,
+                                    corrupt_every=ce(N // 4)))
                 assert (wls[-1].crs == wls[0].crs).all()
         else:
-            wls = [Workload(eng, ty=ty, N=N, m=m, n=n, seed=20241220 + seed_off + rank, device=self.dev)]
+            wls = [Workload(eng, ty=ty, N=N, m=m, n=n, seed=20241220 + seed_off + rank, device=self.dev,
+                            corrupt_every=ce(N))]
 
         pparts = [dict(ty=w.ty, N=w.N, m=w.m, n=w.n, X=w.X, Y=w.Y, A=w.A, B=w.B, Gamma=w.Gamma, R=w.R, S=w.S, T=w.T,
                        xcoms=w.xcoms, ycoms=w.ycoms, pi=w.pi, theta=w.theta) for w in wls]
@@ -315,7 +357,7 @@ class Bench:
             if mode == "exact":
                 if mixed:
                     eng.verify_mixed_dev(vparts)
-                    eng.sync()  # the verdict tensors are written on the children's streams; the parent joins them
+                    eng.sync()  # the verdict tensors are written on the context's stream (merged launches); join before reading
                 else:
                     wls[0].verify()
                 # rank-combined verdict: number of rejected proofs over all ranks (one 8-byte all-reduce over RCCL)
@@ -359,6 +401,22 @@ class Bench:
 
         res = {"value": N * world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                "equations_per_gpu": N, "workload": self.describe(log2n, curve, ty, mixed, mode, m, n)}
+        if dist is not None and mode == "exact":
+            # the rank-combined verdict sees a corrupted proof that exists on ONE rank only (the last): every rank must
+            # come out of the all-reduce with exactly that rank's count
+            for w in wls:
+                w.prove()
+            expect = 0
+            if rank == world - 1:
+                expect = sum(len(w.corrupt()) for w in wls)
+            for w in wls:
+                w.verify()
+            eng.sync()
+            seen = allreduce_failures(sum((w.ok == 0).sum() for w in wls), device=self.coll_dev)
+            tt = torch.tensor([expect], dtype=torch.int64, device=self.coll_dev)
+            dist.all_reduce(tt)
+            assert seen == int(tt.item()) and seen > 0, "rank-combined verdict: %s seen, %s corrupted on the last rank" % (seen, int(tt.item()))
+            res["rank_combined_check"] = {"corrupted_on_rank": world - 1, "failures_seen_by_every_rank": int(seen)}
         if roofline and rank == 0:
             res["roofline"] = self.roofline(eng, wls, one_step, N, curve, config_tag(log2n, curve, ty, mixed, mode))
         for w in wls:
@@ -436,6 +494,7 @@ class Bench:
         eng.sync()
         prof = eng.prof_get()
         work = eng.prof_get_work()
+        clocks = eng.prof_get_clock()
         eng.prof_enable(False)
         tot = sum(p[1] for p in prof) or 1.0
         name, ms, launches = max(prof, key=lambda p: p[1])
@@ -443,7 +502,7 @@ class Bench:
         bpu = sum(w.bytes_per_unit() * w.N for w in wls) / N
         achieved = N * bpu / avg_s / 1e9
         traffic, src = pmc_traffic(tag, name)
-        alu = alu_roofline(work, {p[0]: p[1] for p in prof}, curve, name)
+        alu = alu_roofline(work, {p[0]: p[1] for p in prof}, curve, name, clocks)
         if "fq_muls_per_step" in alu:
             alu["fq_muls_per_unit"] = alu["fq_muls_per_step"] / N
         return {
@@ -461,6 +520,7 @@ class Bench:
             "bytes_per_unit": bpu,
             "kernel_share_of_step": ms / tot,
             "kernels_ms": {p[0]: round(p[1], 3) for p in prof},
+            "kernels_ms_sum": round(tot, 3),
             "note": "integer-ALU bound path (SURVEY.md 8d): HBM fraction is ~1e-4 by construction; see alu",
             "alu": alu,
         }
@@ -485,7 +545,7 @@ def inproc_main(args):
         sys.stderr.write("bench.py: --gpus %d --inproc but %d device(s) visible\n" % (nsh, torch.cuda.device_count()))
         sys.exit(3)
     if not args.log2n:
-        args.log2n = 16 if nsh == 1 else max(18 - (nsh.bit_length() - 1), 10)
+        args.log2n = 16
     per = 1 << args.log2n
     N = per * nsh
     if not args.steps:
@@ -533,7 +593,7 @@ def inproc_main(args):
            "GS proofs+verifies/sec (curve %d type %d)" % (args.curve, args.type),
            "value": N * args.steps / dt, "unit": "proofs+verifies/s", "n_gpus": len(set(devices)), "steps": args.steps,
            "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "strong" if nsh > 1 else "weak", "vs_baseline": None,
+           "scaling": "weak", "vs_baseline": None,
            "dtype": "u32 limbs (381-bit Montgomery)" if args.curve == 0 else "u32 limbs (254-bit Montgomery)",
            "data": "synthetic",
            "config": {"workload": "2^%d independent equations per shard, m=%d n=%d, commit_and_prove+verify(exact), one "
@@ -551,7 +611,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="0 = default for the configuration (~12 s of GPU work)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2n", type=int, default=0,
-                    help="equations per GPU (2^k); default 16 at one GPU, 18 - log2(gpus) otherwise (configs[3])")
+                    help="equations per GPU (2^k); default 16 at every N (weak scaling); configs[3] = --gpus 8 --log2n 15")
     ap.add_argument("--m", type=int, default=4)
     ap.add_argument("--n", type=int, default=4)
     ap.add_argument("--curve", type=int, default=0)
@@ -607,7 +667,7 @@ def main():
     coll_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
 
     if not args.log2n:
-        args.log2n = 16 if world == 1 else max(18 - (world.bit_length() - 1), 10)
+        args.log2n = 16  # per GPU, whatever the number of ranks: one weak-scaling curve through the N = 1 headline point
     N = 1 << args.log2n
     if not args.steps:  # ~12 s of timed GPU work at the measured ~135 k units/s/GPU, at least 3 steps
         args.steps = max(3, min(200, int(12.0 * 135e3 / N)))
@@ -626,16 +686,23 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True,
-        # one GPU: its own batch; several: the 2^18 batch of configs[3] split over the ranks (total fixed)
-        "scaling": "strong" if world > 1 else "weak",
+        # the per-GPU batch is the same at every N (2^16 by default): total work grows with the ranks
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32 limbs (381-bit Montgomery)" if args.curve == 0 else "u32 limbs (254-bit Montgomery)",
         "data": "synthetic",
         "config": {"workload": main_res["workload"], "curve": "BLS12-381" if args.curve == 0 else "BN254",
                    "equations_per_gpu": N, "total_equations": N * world,
+                   # what the collective library sees / the devices the ranks actually sit on (a gloo rehearsal on one
+                   # GPU reports distinct_devices = 1: its numbers mean nothing as a scaling point)
+                   "collective_backend": (dist.get_backend() if dist is not None else None),
+                   "rccl_ranks": (world if dist is not None and dist.get_backend() == "nccl" else 0),
+                   "distinct_devices": distinct_devices(dist, local, world, coll_dev),
                    "parallelism": "equation-sharded x%d%s" % (world, ", failure counts all-reduced (RCCL) every step"
                                                               if world > 1 and args.mode == "exact" else "")},
     }
+    if "rank_combined_check" in main_res:
+        res["config"]["rank_combined_check"] = main_res["rank_combined_check"]
     if rank == 0:
         res["roofline"] = main_res.get("roofline")
         default_cfg = args.curve == 0 and args.type == 0 and not args.mixed and args.mode == "exact"
@@ -652,11 +719,12 @@ def main():
                 also[tag] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": st, "workload": r["workload"],
                              "dominant_kernel": rf.get("kernel"), "alu_frac": (rf.get("alu") or {}).get("frac"),
                              "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
-                             "kernels_ms": rf.get("kernels_ms")}
+                             "kernels_ms": rf.get("kernels_ms"), "kernels_ms_sum": rf.get("kernels_ms_sum"),
+                             "alu_clock_ghz": (rf.get("alu") or {}).get("clock_ghz")}
             also["2p16_ppe_hostptr"] = b.run_hostptr(16, steps=3)
             also["2p12_ppe_hostptr"] = b.run_hostptr(12, steps=20)
             res["also"] = also
-        if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
+        if not args.no_cpu:  # rank 0 times the CPU baseline on the host cores it is granted, at every N
             threads, _ = host_cores()
             sample = args.cpu_sample or max(128 * threads, 256)   # ~10-30 s of CPU work on the granted host cores
             res["cpu_baseline"] = cpu_baseline(sample, threads)

@@ -26,11 +26,12 @@ SYMBOLS = [
     "gs_multi_pairing_batch", "gs_multi_pairing_batch_dev", "gs_gt_pow_batch_dev",
     "gs_wire_sizes", "gs_wire_encode_g1", "gs_wire_encode_g2", "gs_wire_decode_g1", "gs_wire_decode_g2",
     "gs_wire_encode_fr", "gs_wire_decode_fr", "gs_wire_encode_gt", "gs_wire_decode_gt",
-    "gs_prof_enable", "gs_prof_reset", "gs_prof_get", "gs_prof_get_work",
+    "gs_validate_points", "gs_validate_points_dev",
+    "gs_prof_enable", "gs_prof_reset", "gs_prof_get", "gs_prof_get_work", "gs_prof_get_clock",
     "gs_ctx_create_multi", "gs_multi_destroy", "gs_multi_ndev", "gs_multi_ctx", "gs_multi_last_error",
     "gs_multi_uses_rccl", "gs_multi_shard", "gs_multi_set_crs", "gs_multi_prove_batch", "gs_multi_verify_batch",
     "gs_multi_verify_batch_rlc",
-    "gs_ctx_create_multi_ex", "gs_multi_exchange_note", "gs_multi_sync", "gs_multi_prove_batch_dev",
+    "gs_ctx_create_multi_ex", "gs_multi_exchange_note", "gs_multi_sync", "gs_multi_set_option", "gs_multi_prove_batch_dev",
     "gs_multi_verify_batch_dev", "gs_multi_verify_batch_rlc_dev", "gs_gt_finalize_dev",
     "gs_prove_mixed_dev", "gs_prove_mixed", "gs_verify_mixed_dev", "gs_verify_mixed",
 ]
@@ -135,6 +136,15 @@ class Engine:
 
     def close(self):
         if self.ctx:
+            # registrations are process-wide and outlive the context: release what THIS engine registered while the
+            # arrays are still alive (a stale start -> bytes entry would make a later array that lands on the same
+            # addresses pass for page-locked and be moved by DMA against a dead registration)
+            for addr in list(getattr(self, "_registered", {})):
+                try:
+                    self.lib.gs_host_unregister(self.ctx, ctypes.c_void_p(addr))
+                except Exception:
+                    pass
+                self._registered.pop(addr, None)
             self.lib.gs_ctx_destroy(self.ctx)
             self.ctx = ctypes.c_void_p()
 
@@ -167,10 +177,18 @@ class Engine:
     def host_register(self, arr):
         """Page-lock a numpy array the caller reuses across host-pointer calls (gs_host_register): the pipeline then
         moves it by DMA directly, without the staging copy."""
-        self._chk(self.lib.gs_host_register(self.ctx, ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes)))
+        addr = arr.ctypes.data
+        self._chk(self.lib.gs_host_register(self.ctx, ctypes.c_void_p(addr), ctypes.c_size_t(arr.nbytes)))
+        # the registration must not outlive the memory: hold the array (for host_buffer() that is the mmap) until
+        # host_unregister / close (ADVICE r3)
+        if not hasattr(self, "_registered"):
+            self._registered = {}
+        self._registered[addr] = arr
 
     def host_unregister(self, arr):
-        self._chk(self.lib.gs_host_unregister(self.ctx, ctypes.c_void_p(arr.ctypes.data)))
+        addr = arr.ctypes.data
+        self._chk(self.lib.gs_host_unregister(self.ctx, ctypes.c_void_p(addr)))
+        getattr(self, "_registered", {}).pop(addr, None)
 
     def set_option(self, key, value):
         """Planner override (include/gs_amd.h, gs_set_option): miller_twin, miller_ch, var_tm, var_mo, var_w, red_k, coop_fe, line_tables,
@@ -533,6 +551,17 @@ class Engine:
                                                  _p(ok)))
         return out, ok
 
+    def validate_points(self, group, pts):
+        """ok[i] = 1 iff point i (boundary limbs; group 1 = G1, 2 = G2) is canonical, on the curve (or the identity)
+        and in the prime-order subgroup (gs_validate_points)."""
+        pts = np.ascontiguousarray(pts).view(np.uint8).reshape(-1)
+        per = self.G1 if group == 1 else self.G2
+        assert group in (1, 2) and pts.size % per == 0
+        n = pts.size // per
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.gs_validate_points(self.ctx, group, ctypes.c_size_t(n), _p(pts), _p(ok)))
+        return ok
+
     # -- profiling hook ---------------------------------------------------------------
     def prof_enable(self, on=True):
         self.lib.gs_prof_enable(self.ctx, 1 if on else 0)
@@ -560,6 +589,17 @@ class Engine:
             lanes, work = ctypes.c_uint64(), ctypes.c_uint64()
             self._chk(self.lib.gs_prof_get_work(self.ctx, i, ctypes.byref(lanes), ctypes.byref(work)))
             out[name] = (lanes.value, work.value)
+        return out
+
+    def prof_get_clock(self):
+        """{kernel name: GHz} -- the clock the profiled launches ran at, stamped inside them (s_memtime /
+        s_memrealtime per wave, gs_prof_get_clock); absent for kernels that are not segmented launches."""
+        out = {}
+        for i, (name, _, _) in enumerate(self.prof_get()):
+            ghz = ctypes.c_double()
+            self._chk(self.lib.gs_prof_get_clock(self.ctx, i, ctypes.byref(ghz)))
+            if ghz.value > 0:
+                out[name] = ghz.value
         return out
 
 
@@ -607,6 +647,8 @@ class MultiEngine:
             raise GsError(rc, (self.lib.gs_multi_last_error(self.h) or b"").decode())
 
     def set_option(self, key, value):
+        if key.startswith("exchange_"):  # options of the multi-GPU layer itself (gs_multi_set_option)
+            return self._chk(self.lib.gs_multi_set_option(self.h, key.encode(), int(value)))
         for i in range(len(self.devices)):
             ctx = ctypes.c_void_p(self.lib.gs_multi_ctx(self.h, i))
             if self.lib.gs_set_option(ctx, key.encode(), int(value)) != 0:

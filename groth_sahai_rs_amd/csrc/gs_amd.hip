@@ -46,6 +46,8 @@ struct ProfEntry {
   uint64_t n = 0;
   uint64_t lanes = 0;  // lane-tasks launched
   uint64_t work = 0;   // kernel-specific work items (scalars, slots, pairs ...; = lanes when no hint was given)
+  // clock stamps of the segmented launches (k_seg): sums over their waves of d s_memtime / d s_memrealtime
+  double cyc = 0, rt = 0;
 };
 
 // Everything derived from one CRS on one device: immutable once built, shared (reference-counted) by every context of
@@ -117,6 +119,10 @@ struct gs_ctx {
   // mixed calls: launches are recorded per part and merged (launch_seg / replay); scratch buffers get a per-part tag;
   // the lane-shape planners see the batch size the merged launches will have
   struct Recorder* rec = nullptr;
+  // 1: GLV / psi-GLS scalar multiplications (r-torsion points only, as arkworks' deserialisation guarantees); 0: every
+  // variable-base scalar multiplication is a plain signed-window double-and-add lane (k_var.plain): ANY curve point,
+  // like the reference's Com::scalar_mul (data_structures.rs:336-342), ~2.5x the variable-base work
+  bool endo = true;
   int var_tab = -1;      // verifier's Gamma^T c on shared per-base window tables: -1 planned (large arities), 0, 1
   int mixed_merge = -1;  // -1 planned (merge while the parts cannot fill the chip on their own), 0 never, 1 always
   int scratch_tag = 0;
@@ -124,7 +130,25 @@ struct gs_ctx {
   hipStream_t copy_stream2 = nullptr, copy_out_stream = nullptr, copy_out_stream2 = nullptr;  // two per direction
   hipEvent_t pev2[16] = {nullptr};
   hipEvent_t pev_ready = nullptr;
+  // buffers a regrow or a plan eviction would have freed WHILE a mixed call records its launches (c->rec): the recorded
+  // argument packs hold raw device pointers, so nothing is freed until the replay has been enqueued and drained
+  std::vector<void*> deferred_free;
+  unsigned long long* stamp = nullptr;  // 3 x u64 on the device: the clock stamps of the launch being profiled
 };
+
+// Every live context of the process (gs_ctx_create .. gs_ctx_destroy): page-locked caller ranges are process-wide
+// (g_reg below), so releasing one has to drain the copy queues of EVERY context that may be moving it -- the shards of
+// a gs_multi context are contexts of their own.
+static std::mutex g_ctx_mu;
+static std::vector<gs_ctx*> g_ctx_all;
+// all DMA and kernels of one context done (its compute stream, side streams and the four copy streams)
+static void drain_ctx(gs_ctx* c) {
+  hipStreamSynchronize(c->stream);
+  for (hipStream_t st : c->side)
+    if (st) hipStreamSynchronize(st);
+  for (hipStream_t st : {c->copy_stream, c->copy_stream2, c->copy_out_stream, c->copy_out_stream2})
+    if (st) hipStreamSynchronize(st);
+}
 
 static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
   if (c) {
@@ -151,12 +175,18 @@ static int fail(gs_ctx* c, int code, const char* what, hipError_t e = hipSuccess
 static int ensure(gs_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return GS_OK;
   if (b.p) {  // growing: kernels already enqueued may still read the old buffer
-    if (c) {
-      hipStreamSynchronize(c->stream);
-      for (hipStream_t st : c->side)
-        if (st) hipStreamSynchronize(st);
+    if (c && c->rec) {
+      // recording: nothing has been launched, a sync protects nothing -- the launches that will read the old buffer
+      // are in the recorder.  Park it; mixed_run / mixed_host release the list after the replay.
+      c->deferred_free.push_back(b.p);
+    } else {
+      if (c) {
+        hipStreamSynchronize(c->stream);
+        for (hipStream_t st : c->side)
+          if (st) hipStreamSynchronize(st);
+      }
+      hipFree(b.p);
     }
-    hipFree(b.p);
   }
   b.p = nullptr;
   b.cap = 0;
@@ -310,11 +340,16 @@ struct HostPipe {
   int out_order[16], n_out = 0;  // output arrays in the order their D2H went out (= the order they arrive)
   int n = 0;
   bool trace = false;
+  bool begun = false, finished = false;  // begin() has enqueued work on the copy streams / finish() has waited for all of it
   int split = 2;  // DMA transfers per array and direction (two copy streams: two SDMA engines)
   std::chrono::steady_clock::time_point t0;
   explicit HostPipe(gs_ctx* ctx) : c(ctx) {}
   ~HostPipe() {
     for (int i = 0; i < n; i++) CopyPool::wait(&arr[i].left);  // no worker may still touch the caller's memory
+    // A call that failed between begin() and the end of finish() returns with H2D / D2H still queued against the caller's
+    // (possibly page-locked) arrays and against stage.* buffers the next call will overwrite: nothing may be in flight
+    // when the caller gets the error back and unwinds (unregisters, frees).
+    if (begun && !finished) drain_ctx(c);
     for (int i = 0; i < 16; i++)
       for (hipEvent_t ev : {ev1[i], ev2[i]})
         if (ev) hipEventDestroy(ev);
@@ -360,6 +395,7 @@ struct HostPipe {
   // device slots, workers; then the staging copies start, inputs in the order `order` lists them.  `base`: where this
   // pipe's region of the pinned buffer begins (several pipes of one mixed call share the buffer)
   int begin(const int* order, int norder, size_t base = 0, bool reserve = true) {
+    begun = true;
     t0 = std::chrono::steady_clock::now();
     trace = getenv("GS_PIPE_TRACE") != nullptr;
     if (const char* e = getenv("GS_COPY_SPLIT")) split = std::max(1, std::min(2, atoi(e)));
@@ -407,6 +443,7 @@ struct HostPipe {
     if (trace) fprintf(stderr, "[pipe] %7.2f ms begin done (%zu bytes of staging)\n", ms(), total);
     return GS_OK;
   }
+  // (begun is set at the top of begin(): a begin() that fails half way has already queued copies)
   // one array across PCIe, in `split` pieces on as many copy streams; ev is recorded (on s0) behind all of them
   int xfer(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s0, hipStream_t s1, hipEvent_t ev,
            hipEvent_t ev_b) {
@@ -485,6 +522,9 @@ struct HostPipe {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) CopyPool::wait(&arr[i].left);
+    // (every D2H was waited for through its event above; the H2D queues were waited for by the kernels that the
+    // stream sync has just seen finish)
+    finished = true;
     if (trace) fprintf(stderr, "[pipe] %7.2f ms done\n", ms());
     return GS_OK;
   }
@@ -698,7 +738,12 @@ template <class Body, class... A> static int go_seg(gs_ctx* c, const LaunchRec* 
   }
   if (lanes == 0) return GS_OK;
   hipStream_t st = c->cur ? c->cur : c->stream;
-  if (c->prof) hipEventRecord(c->ev0, st);
+  if (c->prof) {
+    if (!c->stamp && hipMalloc((void**)&c->stamp, 3 * sizeof(unsigned long long)) != hipSuccess) c->stamp = nullptr;
+    if (c->stamp) hipMemsetAsync(c->stamp, 0, 3 * sizeof(unsigned long long), st);
+    S.stamp = c->stamp;
+    hipEventRecord(c->ev0, st);
+  }
   hipLaunchKernelGGL((k_seg<Body, A...>), dim3((unsigned)(lanes / block)), dim3(block), 0, st, S);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, GS_ERR_DEVICE, r[0]->name.c_str(), e);
@@ -714,6 +759,10 @@ template <class Body, class... A> static int go_seg(gs_ctx* c, const LaunchRec* 
     p.n += 1;
     p.lanes += tot;
     p.work += work;
+    if (c->stamp) {
+      unsigned long long h[3] = {0, 0, 0};
+      if (hipMemcpy(h, c->stamp, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) p.cyc += (double)h[0], p.rt += (double)h[1];
+    }
   }
   return GS_OK;
 }
@@ -810,6 +859,7 @@ static inline uint8_t tb_w(int c) { return c ? 4 : 2; }
 constexpr size_t GS_PLAN_CAP = 256;
 static int plan_evict(gs_ctx* c) {
   if (c->plans.size() <= GS_PLAN_CAP) return GS_OK;
+  if (c->rec) return GS_OK;  // recorded launches hold pointers into the cached tables: evict on a later call
   hipStreamSynchronize(c->stream);
   for (hipStream_t st : c->side)
     if (st) hipStreamSynchronize(st);
@@ -976,7 +1026,7 @@ static double wave_rounds(const gs_ctx* c, double waves, bool g2) {
 static int pick_tm(const gs_ctx* c, size_t N, int T, int outputs, bool g2, int share) {
   // `share` of the `outputs` run over the same bases (share_tables() can give them one table build per lane): the
   // group size is chosen together with the outputs per lane and the window width that share_tables() will then pick
-  if (T < 2) return 1;
+  if (T < 2 || !c->endo) return 1;  // (no endomorphisms: one plain lane per term)
   if (c->var_tm > 0) {  // forced: the balanced group size is what runs
     int ng = (T + c->var_tm - 1) / c->var_tm;
     return (T + ng - 1) / ng;
@@ -1270,6 +1320,9 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     c->work_hint = N * sp.var.size();  // terms
     RC((launch_seg<k_var_tab<C, F, 8, TW>>(c, (std::string("k_var_tab8") + tag).c_str(), tot, 64, tot, (int)sp.grp.size(), dgrp,
                                            dvar, pool, pool_n, (Jac<F>*)part, sp.nslots, (const Aff<F>*)tabs, sp.tab_bases)));
+  } else if (sp.tm <= 1 && !c->endo) {
+    RC((launch_seg<k_var<C, F, false>>(c, (std::string("k_var.plain") + tag).c_str(), N * sp.var.size(), 64, N * sp.var.size(),
+              (int)sp.var.size(), dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots)));
   } else if (sp.tm <= 1) {
     RC(launch_seg<k_var<C, F>>(c, (std::string("k_var") + tag).c_str(), N * sp.var.size(), 64, N * sp.var.size(),
               (int)sp.var.size(), dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots));
@@ -1788,7 +1841,8 @@ template <class C> struct Impl {
     // lanes over shared per-base window tables -- measured in profiles/r3/large_arity_334.json
     // (planned only while the tables -- N x 2 m bases x 128 entries, affine + Jacobian staging -- stay below 8 GB)
     const double tab8_bytes = (double)N * 2.0 * m * 128.0 * (double)(sizeof(A1) + sizeof(Jac<F1>));
-    const bool tab8 = c->var_tab == 1 || (c->var_tab < 0 && wide_prep(m, n) && n >= 32 && tab8_bytes <= 8e9);
+    // (the shared base tables are read by endomorphism-decomposed lanes: not with "endo" off)
+    const bool tab8 = c->endo && (c->var_tab == 1 || (c->var_tab < 0 && wide_prep(m, n) && n >= 32 && tab8_bytes <= 8e9));
     build_verify(vp, c->curve, ty, m, n, pm, budget, twin, tab8 ? -1 : pick_tm(c, fillN(c, N), m, 2 * n, false, n),
                  c->line_tables);
     // G1-side points
@@ -2344,6 +2398,10 @@ template <class C> struct WireImpl {
     RC(st.back(pts, dout, n * pb));
     return st.back(ok, dok, n);
   }
+  // on-curve + r-torsion check of in-memory points (device pointers)
+  template <class F> static int validate_pts_dev(gs_ctx* c, size_t n, const void* pts, uint8_t* ok) {
+    return launch(c, "k_validate_pts", k_validate_pts<C, F>, n, 64, n, (const uint8_t*)pts, ok);
+  }
   // what: 0 Fr, 1 GT
   static int fields(gs_ctx* c, int what, int dir, int validate, size_t n, const void* in, void* out, uint8_t* ok) {
     if (n == 0) return GS_OK;
@@ -2425,14 +2483,24 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
     if (hipEventCreateWithFlags(&c->sev[i], hipEventDisableTiming) != hipSuccess) c->overlap = false;
   if (!c->overlap) c->side[0] = nullptr;
   if (const char* e = getenv("GS_OVERLAP")) c->overlap = c->overlap && atoi(e) != 0;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctx_all.push_back(c);
+  }
   *out = c;
   return GS_OK;
 }
 
 void gs_ctx_destroy(gs_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctx_all.erase(std::remove(g_ctx_all.begin(), g_ctx_all.end(), c), g_ctx_all.end());
+  }
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  drain_ctx(c);
+  for (void* p : c->deferred_free) hipFree(p);
+  if (c->stamp) hipFree(c->stamp);
   for (auto& kv : c->scratch)
     if (kv.second.p) hipFree(kv.second.p);
   for (hipStream_t st : c->side)
@@ -2474,6 +2542,8 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
   } else if (k == "var_tab") {
     if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "var_tab: -1 (planned), 0 Straus lanes, 1 shared per-base window tables");
     c->var_tab = value;
+  } else if (k == "endo") {
+    c->endo = value != 0;
   } else if (k == "mixed_merge") {
     if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "mixed_merge: -1 (planned), 0 parts one after the other, 1 merged launches");
     c->mixed_merge = value;
@@ -2536,7 +2606,17 @@ int gs_host_unregister(gs_ctx* c, void* ptr) {
   if (!ptr) return GS_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_reg_mu);
   if (!g_reg.count((const uint8_t*)ptr)) return fail(c, GS_ERR_ARG, "gs_host_unregister: not registered here");
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // nothing of this context may still be moving the buffer
+  // Nothing may still be moving the buffer: the registry is process-wide, so EVERY live context is drained -- its
+  // compute stream and its copy queues (a D2H is only gated on the compute stream, not finished with it), the shards
+  // of a gs_multi context included (they are contexts of their own on their own devices).
+  {
+    std::lock_guard<std::mutex> lk2(g_ctx_mu);
+    for (gs_ctx* o : g_ctx_all) {
+      hipSetDevice(o->device);
+      drain_ctx(o);
+    }
+    hipSetDevice(c->device);
+  }
   hipError_t e = hipHostUnregister(ptr);
   g_reg.erase((const uint8_t*)ptr);
   if (e != hipSuccess) {
@@ -2796,8 +2876,9 @@ int gs_verify_batch(gs_ctx* c, int ty, size_t N, int m, int n, const void* A, co
 // on one), and the extra queues' scratch reservations slowed LATER large batches on the parent fourfold (2^16 PPE
 // 320 -> 1400 ms).  What does fill the chip for a mixed batch of a few thousand equations is merging the lanes of
 // all parts into single launches (segmented launches, section 4.3 of DESIGN.md).
-// Record every part's launches (nothing is enqueued yet), then replay them merged.  Under the kernel profile
-// (gs_prof_enable) and for a single part the parts simply run one after the other.
+// Record every part's launches (nothing is enqueued yet), then replay them merged.  A single part simply runs.  The
+// kernel profile (gs_prof_enable) times the MERGED launches themselves (go_seg: HIP events around each k_seg launch, under
+// the name of its first segment), so that a mixed step's per-kernel times add up to the step that is timed.
 // Merged launches pay off while the parts' own launches leave SIMDs idle; from ~2^15 equations on every part fills the
 // chip by itself and separate launches with per-part lane shapes are as fast (measured: profiles/r3/mixed_merge.txt).
 static bool merge_parts(const gs_ctx* c, size_t total_n) {
@@ -2806,9 +2887,17 @@ static bool merge_parts(const gs_ctx* c, size_t total_n) {
   // 193 against 182 ms at 2^15, where every part fills the chip with its own lane shapes)
   return total_n <= 16 * c->simd_slots;
 }
+// buffers parked by ensure() during a recording: the replayed launches may read them, so they go after a stream sync
+static int release_deferred(gs_ctx* c, int rc) {
+  if (c->deferred_free.empty()) return rc;
+  hipStreamSynchronize(c->stream);
+  for (void* p : c->deferred_free) hipFree(p);
+  c->deferred_free.clear();
+  return rc;
+}
 extern "C++" {
 template <class FN> static int mixed_run(gs_ctx* c, int nparts, size_t total_n, FN part_fn) {
-  if (nparts <= 1 || c->prof || c->rec || !merge_parts(c, total_n)) {
+  if (nparts <= 1 || c->rec || !merge_parts(c, total_n)) {
     for (int i = 0; i < nparts; i++) RC(part_fn(i));
     return GS_OK;
   }
@@ -2825,8 +2914,8 @@ template <class FN> static int mixed_run(gs_ctx* c, int nparts, size_t total_n, 
   c->rec = nullptr;
   c->fill_n = 0;
   c->scratch_tag = 0;
-  RC(rc);  // (a failed part: nothing was launched)
-  return replay(c, R);
+  if (rc == GS_OK) rc = replay(c, R);  // (a failed part: nothing was launched)
+  return release_deferred(c, rc);
 }
 }  // extern "C++"
 int gs_prove_mixed_dev(gs_ctx* c, int nparts, const gs_prove_part* p) {
@@ -2859,7 +2948,7 @@ extern "C++" {
 template <class ARGS, class STAGE, class RUN>
 static int mixed_host(gs_ctx* c, std::vector<ARGS>& a, size_t total_n, STAGE stage, RUN run) {
   const int np = (int)a.size();
-  if (np <= 1 || c->prof || !merge_parts(c, total_n)) {
+  if (np <= 1 || !merge_parts(c, total_n)) {
     for (int i = 0; i < np; i++) {
       HostPipe h(c);
       RC(stage(c, a[i], h, (size_t)0, true));
@@ -2911,8 +3000,8 @@ static int mixed_host(gs_ctx* c, std::vector<ARGS>& a, size_t total_n, STAGE sta
     }
   }
   c->scratch_tag = 0;
-  if (rc != GS_OK) hipStreamSynchronize(c->stream);
-  return rc;
+  if (rc != GS_OK) drain_ctx(c);  // uploads / downloads of the parts that did start (not only c->stream)
+  return release_deferred(c, rc);
 }
 }  // extern "C++"
 int gs_prove_mixed(gs_ctx* c, int nparts, const gs_prove_part* p) {
@@ -3005,6 +3094,13 @@ int gs_verify_statement(gs_ctx* c, int ty, size_t E, int m, int n, const void* A
 int gs_g1_mul_batch_dev(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
   RC(check_ctx(c, false));
   if (n == 0) return GS_OK;
+  if (!c->endo) {  // plain double-and-add lanes: any curve point (gs_set_option "endo" 0)
+    if (c->curve == 0)
+      return launch(c, "k_smul_batch.plain.g1", k_smul_batch<Bls12_381, Fq<Bls12_381>, false>, n, 64, n, (const uint8_t*)p,
+                    bc, (const Fr<Bls12_381>*)k, (uint8_t*)out);
+    return launch(c, "k_smul_batch.plain.g1", k_smul_batch<Bn254, Fq<Bn254>, false>, n, 64, n, (const uint8_t*)p, bc,
+                  (const Fr<Bn254>*)k, (uint8_t*)out);
+  }
   if (c->curve == 0)
     return launch(c, "k_smul_batch.g1", k_smul_batch<Bls12_381, Fq<Bls12_381>>, n, 64, n, (const uint8_t*)p, bc,
                   (const Fr<Bls12_381>*)k, (uint8_t*)out);
@@ -3014,6 +3110,13 @@ int gs_g1_mul_batch_dev(gs_ctx* c, size_t n, const void* p, int bc, const void* 
 int gs_g2_mul_batch_dev(gs_ctx* c, size_t n, const void* p, int bc, const void* k, void* out) {
   RC(check_ctx(c, false));
   if (n == 0) return GS_OK;
+  if (!c->endo) {  // plain double-and-add lanes: any curve point (gs_set_option "endo" 0)
+    if (c->curve == 0)
+      return launch(c, "k_smul_batch.plain.g2", k_smul_batch<Bls12_381, Fp2<Bls12_381>, false>, n, 64, n, (const uint8_t*)p,
+                    bc, (const Fr<Bls12_381>*)k, (uint8_t*)out);
+    return launch(c, "k_smul_batch.plain.g2", k_smul_batch<Bn254, Fp2<Bn254>, false>, n, 64, n, (const uint8_t*)p, bc,
+                  (const Fr<Bn254>*)k, (uint8_t*)out);
+  }
   if (c->curve == 0)
     return launch(c, "k_smul_batch.g2", k_smul_batch<Bls12_381, Fp2<Bls12_381>>, n, 64, n, (const uint8_t*)p, bc,
                   (const Fr<Bls12_381>*)k, (uint8_t*)out);
@@ -3207,6 +3310,32 @@ int gs_wire_decode_g2(gs_ctx* c, size_t n, int compressed, int validate, const u
   return WIRE_DISPATCH((WireImpl<Bls12_381>::dec_pts<Fp2<Bls12_381>>(c, n, compressed, validate, in, pts, ok)),
                        (WireImpl<Bn254>::dec_pts<Fp2<Bn254>>(c, n, compressed, validate, in, pts, ok)));
 }
+// ---- subgroup safety at the boundary ------------------------------------------------------
+int gs_validate_points_dev(gs_ctx* c, int group, size_t n, const void* pts, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  if (group != 1 && group != 2) return fail(c, GS_ERR_ARG, "group: 1 (G1) or 2 (G2)");
+  if (n == 0) return GS_OK;
+  if (!pts || !ok) return fail(c, GS_ERR_ARG, "null pointer");
+  if (c->curve == 0)
+    return group == 1 ? WireImpl<Bls12_381>::validate_pts_dev<Fq<Bls12_381>>(c, n, pts, ok)
+                      : WireImpl<Bls12_381>::validate_pts_dev<Fp2<Bls12_381>>(c, n, pts, ok);
+  return group == 1 ? WireImpl<Bn254>::validate_pts_dev<Fq<Bn254>>(c, n, pts, ok)
+                    : WireImpl<Bn254>::validate_pts_dev<Fp2<Bn254>>(c, n, pts, ok);
+}
+int gs_validate_points(gs_ctx* c, int group, size_t n, const void* pts, uint8_t* ok) {
+  RC(check_ctx(c, false));
+  if (group != 1 && group != 2) return fail(c, GS_ERR_ARG, "group: 1 (G1) or 2 (G2)");
+  if (n == 0) return GS_OK;
+  if (!pts || !ok) return fail(c, GS_ERR_ARG, "null pointer");
+  size_t pb = (group == 1 ? 2 : 4) * sz_fq(c->curve);
+  HostStage st(c);
+  void *din, *dok;
+  RC(st.in(pts, n * pb, &din));
+  RC(st.out(ok, n, &dok));
+  RC(gs_validate_points_dev(c, group, n, din, (uint8_t*)dok));
+  return st.back(ok, dok, n);
+}
+
 int gs_wire_encode_fr(gs_ctx* c, size_t n, const void* fr, uint8_t* out) {
   RC(check_ctx(c, false));
   return WIRE_DISPATCH(WireImpl<Bls12_381>::fields(c, 0, 0, 0, n, fr, out, nullptr),
@@ -3250,6 +3379,14 @@ int gs_prof_get(gs_ctx* c, int idx, char* name, size_t cap, double* ms, uint64_t
   }
   if (ms) *ms = c->prof_map[k].ms;
   if (n) *n = c->prof_map[k].n;
+  return GS_OK;
+}
+// clock (GHz) the launches under entry idx ran at: sum over their waves of d s_memtime / d s_memrealtime x 100 MHz, taken
+// inside those very launches (k_seg stamps); 0 for kernels that are not segmented launches
+int gs_prof_get_clock(gs_ctx* c, int idx, double* ghz) {
+  if (!c || !ghz || idx < 0 || idx >= (int)c->prof_order.size()) return GS_ERR_ARG;
+  const ProfEntry& p = c->prof_map[c->prof_order[idx]];
+  *ghz = p.rt > 0 ? p.cyc / p.rt * 0.1 : 0.0;
   return GS_OK;
 }
 int gs_prof_get_work(gs_ctx* c, int idx, uint64_t* lanes, uint64_t* work) {

@@ -137,6 +137,43 @@ template <class F> GS_JAC void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>&
   r.z = z3;
 }
 
+// ---- fast in-place forms for the scalar-multiplication loops ----------------------------------------------------------
+// G1 on the device: the whole point operation is ONE generated subroutine on fixed registers (gs_pointops_asm.h: no
+// operand moves, no spills, no memory instruction).  The subroutine is the generic branch of the formulas; the edge
+// cases of the addition stay here: either operand the identity, or H = 0 mod p (P = +-Q), found by the 56-bit filter on
+// the two low limbs of H the subroutine hands back -- then the C++ jac_madd runs on the SAVED operands.  Everything else
+// (G2, the CPU twin, builds without the asm calls) takes the C++ formulas.
+template <class F> GS_HD_NOINLINE void jac_madd_edge(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) { jac_madd(r, p, q); }
+template <class F> GS_HD void jac_dbl_ip(Jac<F>& r) { jac_dbl(r, r); }
+template <class F> GS_HD void jac_madd_ip(Jac<F>& r, const Aff<F>& q) { jac_madd(r, r, q); }
+#if defined(GS_POINT_ASM)
+template <class C> GS_HD void jac_dbl_ip(Jac<Fq<C>>& r) {
+  // (Z = 0 stays exactly 0: products with exact zero limbs are exact zeros)
+  if constexpr (C::L == 14)
+    g1_dbl_call_14<C>(r.x.v, r.y.v, r.z.v);
+  else
+    g1_dbl_call_10<C>(r.x.v, r.y.v, r.z.v);
+}
+template <class C> GS_HD void jac_madd_ip(Jac<Fq<C>>& r, const Aff<Fq<C>>& q) {
+  const Jac<Fq<C>> p0 = r;
+  Aff<Fq<C>> qq = q;
+  const bool edge = aff_is_inf(q) || is_zero_limbs(r.z);
+  int32_t h0, h1;
+  if constexpr (C::L == 14)
+    g1_madd_call_14<C>(r.x.v, r.y.v, r.z.v, qq.x.v, qq.y.v, h0, h1);
+  else
+    g1_madd_call_10<C>(r.x.v, r.y.v, r.z.v, qq.x.v, qq.y.v, h0, h1);
+  if (edge || maybe_zero_limbs01<C>(h0, h1)) {  // rare: the first addition of a lane, identity table entries, P = +-Q
+    // (false alarms 2^-35).  `r` and `p0` never have their address taken -- a running value that is only reachable
+    // through a reference is memory at every step -- so the out-of-line routine works on copies made in this branch.
+    Jac<Fq<C>> tp = p0, tr;
+    Aff<Fq<C>> tq = q;
+    jac_madd_edge(tr, tp, tq);
+    r = tr;
+  }
+}
+#endif
+
 template <class F> GS_HD void jac_neg(Jac<F>& r, const Jac<F>& p) {
   r.x = p.x;
   r.y = neg(p.y);
@@ -339,7 +376,10 @@ template <class F> GS_HD_NOINLINE void smul_build_table_n(Jac<F>* tab, const Aff
 }
 
 // out[i] = (i + 1) P in AFFINE form, i < ne: Jacobian chain into `stage`, one inversion for all entries (Montgomery's
-// trick).  P of prime order and ne < r: no multiple is the identity unless P is.
+// trick).  For P of prime order and ne < r no multiple is the identity unless P is -- but this table is built from the
+// VERIFIER's commitment inputs (k_tab_build), i.e. from untrusted boundary data: a low-order or non-subgroup point can
+// make some multiple the identity (Z = 0).  Such entries are skipped in the prefix product (as k_red does) and come out
+// as the affine identity (0, 0), so one bad base cannot poison the shared inversion of its table.
 template <class F> GS_HD_NOINLINE void smul_affine_table(Aff<F>* out, Jac<F>* stage, const Aff<F>& p, int ne) {
   if (aff_is_inf(p)) {
     for (int i = 0; i < ne; i++) out[i].x = zero_of<F>(), out[i].y = zero_of<F>();
@@ -348,11 +388,16 @@ template <class F> GS_HD_NOINLINE void smul_affine_table(Aff<F>* out, Jac<F>* st
   smul_build_table_n(stage, p, ne);
   F acc = one_of<F>();
   for (int i = 0; i < ne; i++) {
-    out[i].x = acc;  // prefix product of the Z before entry i
-    acc = mul(acc, stage[i].z);
+    out[i].x = acc;  // prefix product of the non-zero Z before entry i
+    if (!is_zero_limbs(stage[i].z)) acc = mul(acc, stage[i].z);
   }
   F iv = inv(acc);
   for (int i = ne - 1; i >= 0; i--) {
+    if (is_zero_limbs(stage[i].z)) {
+      out[i].x = zero_of<F>();
+      out[i].y = zero_of<F>();
+      continue;
+    }
     F zi = mul(out[i].x, iv);  // 1 / Z_i
     iv = mul(iv, stage[i].z);
     F z2 = sqr(zi);
@@ -553,8 +598,12 @@ template <class C, class F, int TMAX> GS_HD void jac_msm_straus(Jac<F>& r, const
 }
 // dispatch: endomorphism path where the curve has one (BN curves: the one-term case of the joint routine, whose
 // digit streams come from the lattice decomposition)
-template <class C, class F> GS_HD void jac_smul_any(Jac<F>& r, const Aff<F>& p, const Fr<C>& k) {
-  if constexpr (C::HAS_ENDO && C::IS_BN)
+// ENDO = false: plain signed-window double-and-add (jac_smul), defined on ANY curve point like the reference's
+// Com::scalar_mul (data_structures.rs:336-342); the endomorphism paths are only valid on the r-torsion.
+template <class C, class F, bool ENDO = true> GS_HD void jac_smul_any(Jac<F>& r, const Aff<F>& p, const Fr<C>& k) {
+  if constexpr (!ENDO)
+    jac_smul(r, p, k);
+  else if constexpr (C::HAS_ENDO && C::IS_BN)
     jac_msm_straus<C, F, 1>(r, &p, &k, 1);
   else if constexpr (C::HAS_ENDO)
     jac_smul_endo<C>(r, p, k);
@@ -642,8 +691,13 @@ template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, c
 // runtime's scratch pool only grants while no other queue holds any (it then limits the kernel's resident waves: the
 // same step took 1100-1700 ms instead of 320 ms after a small batch had run reductions on a side stream,
 // profiles/r3/scratch_pool.txt).  The kernels pass a second region of the lane's global workspace.
+#if defined(GS_STRAUS_INLINE)
+#define GS_STRAUS GS_HD
+#else
+#define GS_STRAUS GS_HD_NOINLINE
+#endif
 template <class C, class F, int TMAX, int W>
-GS_HD_NOINLINE void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int nt, Jac<F>* tab) {
+GS_STRAUS void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int nt, Jac<F>* tab) {
   constexpr int NE = 1 << (W - 1);
   for (int t = 0; t < nt; t++) smul_build_table_n(tab + t * NE, ps[t], NE);
   table_global_z<C>(at, tab, NE * nt, zback);  // ONE isomorphic curve for all the terms' tables
@@ -652,13 +706,91 @@ GS_HD_NOINLINE void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int
 // that many lanes share (k_var_tab: one table per (equation, base), true affine entries, zback = 1); `negm` bit t
 // then stands for "-P_t".
 template <class C, class F, int TMAX, int W>
-GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F>* at, const F& zback,
+GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F>* at, const F& zback,
                                    const Aff<F>* const* tabs = nullptr, uint32_t negm = 0) {
   constexpr int NE = 1 << (W - 1);
   Jac<F> r;  // the running sum stays a local (registers): a reference parameter is memory at every step
   if constexpr (C::HAS_ENDO) {
     typedef EndoShape<C, F> E;
     constexpr int ND = E::nd(W);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GS_STRAUS_OLD_LOOP)
+    // ---- device main loop (round 4).  At one wave per SIMD every vector-memory wait is exposed in full, and
+    // s_waitcnt vmcnt counts in order: ANY load a step waits for also waits for everything requested before it.  So:
+    //  * the digits live in LDS (their reads count on lgkmcnt, not vmcnt; rows of an odd number of dwords per lane:
+    //    conflict-free), where the private segment cost a scratch_load_sbyte + vmcnt(0) per table look-up;
+    //  * the table entry of the NEXT non-trivial step is requested before the current addition starts (one step =
+    //    ~6 k instructions: the HBM latency of the lane-contiguous tables disappears behind it) -- which only works
+    //    because nothing else in the loop waits on vmcnt: the G1 point operations are register-only subroutines
+    //    (jac_dbl_ip / jac_madd_ip) and the running sum never has its address taken.
+    constexpr int NSL = E::NS * ND;                       // digits per term
+    constexpr int ROWB = ((TMAX * NSL + 3) / 4 * 4);      // bytes per lane, whole dwords ...
+    constexpr int ROW = ((ROWB / 4) % 2 == 0) ? ROWB + 4 : ROWB;  // ... an ODD number of them
+    constexpr bool LDS_DG = (size_t)ROW * 64 <= 36 * 1024;  // (BN254 G2 with 8 terms does not fit: private frame)
+    __shared__ int8_t sdg[LDS_DG ? ROW * 64 : 4];
+    int8_t ldg[LDS_DG ? 1 : TMAX * NSL];
+    int8_t* const dgp = LDS_DG ? &sdg[(threadIdx.x & 63) * ROW] : ldg;
+    uint32_t sgm = 0;  // bit t * NS + s: stream s of term t is negated
+    for (int t = 0; t < nt; t++) {
+      uint8_t sg1[E::NS];
+      endo_digits<C, W>(dgp + t * NSL, sg1, ks[t], (const Jac<F>*)nullptr);
+      for (int s2 = 0; s2 < E::NS; s2++) sgm |= (uint32_t)(sg1[s2] != 0) << (t * E::NS + s2);
+    }
+    auto digit = [&](int i, int k) -> int {  // slot k = t * NS + s of window i
+      const int idx = (k / E::NS) * NSL + (k % E::NS) * ND + i;
+      if constexpr (LDS_DG) return (int)sdg[(threadIdx.x & 63) * ROW + idx];
+      return (int)ldg[idx];
+    };
+    jac_set_inf(r);
+    const int nk = nt * E::NS;
+    int top = 0;  // highest window with a non-zero digit: short scalars skip their leading doublings
+    for (int k = 0; k < nk; k++)
+      for (int i = ND - 1; i > top; i--)
+        if (digit(i, k) != 0) top = i;
+    auto entry = [&](int i, int k) -> const Aff<F>* {  // (a zero digit requests entry 0: harmless, never used)
+      int a = digit(i, k);
+      a = a < 0 ? -a : a;
+      const int idx = a ? a - 1 : 0, t = k / E::NS;
+      return tabs ? tabs[t] + idx : at + t * NE + idx;
+    };
+    // (limb-wise loads: a struct copy from a pointer is a memcpy into a private-frame temporary that the compiler then
+    // copies again, 16 bytes per load + wait + store)
+    auto ldaff = [](const Aff<F>* p) -> Aff<F> {
+      Aff<F> v;
+      constexpr int NWD = (int)(sizeof(Aff<F>) / sizeof(limb_t));
+      // the tables are global memory: global_load, which counts on vmcnt only -- a FLAT load also counts on lgkmcnt,
+      // and the next digit read from LDS (s_waitcnt lgkmcnt(0)) would then wait for the whole prefetch
+      typedef const __attribute__((address_space(1))) limb_t* gptr;
+      gptr w = (gptr) reinterpret_cast<const limb_t*>(p);
+#pragma unroll
+      for (int q = 0; q < NWD; q++) reinterpret_cast<limb_t*>(&v)[q] = w[q];
+      return v;
+    };
+    Aff<F> e = ldaff(entry(top, 0));
+    for (int i = top; i >= 0; i--) {
+      if (i != top) {
+#pragma unroll 1
+        for (int d4 = 0; d4 < W; d4++) jac_dbl_ip(r);
+      }
+#pragma unroll 1
+      for (int k = 0; k < nk; k++) {
+        Aff<F> en = e;
+        {
+          int ni = i, k2 = k + 1;
+          if (k2 == nk) ni = i - 1, k2 = 0;
+          if (ni >= 0) en = ldaff(entry(ni, k2));  // requested now, consumed after this step's addition
+        }
+        const int a = digit(i, k);
+        if (a != 0) {
+          const int t = k / E::NS, s2 = k % E::NS;
+          Aff<F> u = e;
+          endo_apply<C>(u, s2);
+          if (((a < 0) != (((sgm >> k) & 1) != 0)) != (((negm >> t) & 1) != 0)) u.y = neg(u.y);
+          jac_madd_ip(r, u);
+        }
+        e = en;
+      }
+    }
+#else
     int8_t dg[TMAX][E::NS * ND];
     uint8_t sg[TMAX][E::NS];
     for (int t = 0; t < nt; t++) endo_digits<C, W>(dg[t], sg[t], ks[t], (const Jac<F>*)nullptr);
@@ -671,7 +803,7 @@ GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const 
     for (int i = top; i >= 0; i--) {
       if (i != top) {
 #pragma unroll 1
-        for (int d4 = 0; d4 < W; d4++) jac_dbl(r, r);
+        for (int d4 = 0; d4 < W; d4++) jac_dbl_ip(r);
       }
       for (int t = 0; t < nt; t++)
         for (int s = 0; s < E::NS; s++) {
@@ -680,9 +812,10 @@ GS_HD_NOINLINE void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const 
           Aff<F> e = tabs ? tabs[t][(a < 0 ? -a : a) - 1] : at[t * NE + (a < 0 ? -a : a) - 1];
           endo_apply<C>(e, s);
           if (((a < 0) != (sg[t][s] != 0)) != (((negm >> t) & 1) != 0)) e.y = neg(e.y);
-          jac_madd(r, r, e);
+          jac_madd_ip(r, e);
         }
     }
+#endif
   } else {
     static_assert(C::HAS_ENDO || W == 4, "plain curves: width 4 only");
     constexpr int ND = (FrM<C>::BITS + 3) / 4 + 1;

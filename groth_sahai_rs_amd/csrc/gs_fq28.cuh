@@ -52,6 +52,11 @@ template <class C> struct Fq28 {
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NO_ASM)
 #include "gs_mul28_asm.h"
+#if !defined(GS_NO_ASM_CALL) && !defined(GS_NO_POINT_ASM)
+// whole G1 point operations as subroutines with their own register allocation (gen_pointops_asm.py; used by gs_curve.cuh)
+#include "gs_pointops_asm.h"
+#define GS_POINT_ASM 1
+#endif
 #endif
 
 // ---- lazy linear operations (no carries, no reduction) -------------------------
@@ -583,14 +588,28 @@ template <class C> GS_HD_NOINLINE bool is_zero_slow(const Fq28<C>& a) {
   }
   return z == 0 || e == 0;
 }
+// p^-1 mod 2^56 from the two low limbs of p (Newton: x <- x (2 - p x) doubles the valid bits)
+template <class C> constexpr uint64_t pinv56() {
+  const uint64_t p = (uint64_t)(uint32_t)C::P28[0] | ((uint64_t)(uint32_t)C::P28[1] << 28);
+  uint64_t x = p;  // p * p = 1 mod 8
+  for (int i = 0; i < 6; i++) x *= 2 - p * x;
+  return x & (((uint64_t)1 << 56) - 1);
+}
+// the cheap "cannot be 0 mod p" filter on its own: false = certainly not a multiple of p.  V = k p with |k| < 2^20
+// (every lazily reduced value within the mul contract) forces (V mod 2^56) p^-1 mod 2^56 to be the small signed integer
+// k.  Only limbs 0 and 1 enter (V mod 2^56 needs no carry propagation), and a non-multiple passes with probability
+// 2^-35.  (Rounds 1-3 filtered on 28 bits of the fully carried value: a non-multiple passed with probability 2^-7 PER
+// LANE, i.e. in 39 % of the waves, and every point addition asks this about its H.)
+template <class C> GS_HD bool maybe_zero_limbs01(limb_t v0, limb_t v1) {
+  const uint64_t m56 = ((uint64_t)1 << 56) - 1;
+  uint64_t V = (uint64_t)(int64_t)v0 + ((uint64_t)(int64_t)v1 << 28);
+  uint64_t k = (V * pinv56<C>()) & m56;
+  int64_t ks = (int64_t)(k << 8) >> 8;  // sign-extend 56 bits
+  return !(ks > ((int64_t)1 << 20) || ks < -((int64_t)1 << 20));
+}
 template <class C> GS_HD bool is_zero(const Fq28<C>& a) {
-  // cheap filter first: V = k p with |k| < 2^20 forces (V mod 2^28) * p^-1 mod 2^28 to be the small
-  // signed integer k; a non-multiple of p passes with probability ~2^-7, then the robust test decides
-  Fq28<C> t = norm_full(a);
-  uint32_t k = ((uint32_t)t.v[0] * (0u - C::P28_INV)) & (uint32_t)M28;   // p^-1 = -(-p^-1)
-  int32_t ks = (int32_t)(k << 4) >> 4;                                  // sign-extend 28 bits
-  if (ks > (1 << 20) || ks < -(1 << 20)) return false;
-  return is_zero_slow(a);
+  if (!maybe_zero_limbs01<C>(a.v[0], a.v[1])) return false;
+  return is_zero_slow(a);  // the robust test decides
 }
 template <class C> GS_HD bool eq(const Fq28<C>& a, const Fq28<C>& b) { return is_zero(sub(a, b)); }
 

@@ -95,6 +95,10 @@ template <class... A> using Pack = PackImpl<std::index_sequence_for<A...>, A...>
 template <size_t I, class T> __host__ __device__ __forceinline__ const T& pack_get(const PackLeaf<I, T>& l) { return l.v; }
 template <class... A> struct Segs {
   int n, pad;
+  // clock stamps (kernel profile only, else null): every wave adds its own d s_memtime (shader cycles), d s_memrealtime
+  // (100 MHz) and 1 to stamp[0..2], so that the host reads the clock THIS launch ran at -- sum d memtime / sum d
+  // memrealtime x 100 MHz -- from the launch it has just timed (bench.py: the ALU peak at the kernel's own clock)
+  unsigned long long* stamp;
   size_t lo[MAX_SEG];  // first lane of each segment (multiples of the block size, ascending; lo[0] = 0)
   Pack<A...> a[MAX_SEG];
 };
@@ -102,13 +106,29 @@ template <class Body, class... A, size_t... I>
 __device__ __forceinline__ void seg_call(size_t g, const Pack<A...>& p, std::index_sequence<I...>) {
   Body::run(g, pack_get<I>(p)...);
 }
-template <class Body, class... A> __global__ void __launch_bounds__(64, GS_WPE) k_seg(Segs<A...> S) {
+#ifndef GS_KSEG_ATTR
+#define GS_KSEG_ATTR
+#endif
+template <class Body, class... A> __global__ void __launch_bounds__(64, GS_WPE) GS_KSEG_ATTR k_seg(Segs<A...> S) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int s = 0;
   for (int i = 1; i < S.n; i++)
     if (g >= S.lo[i]) s = i;
   s = __builtin_amdgcn_readfirstlane(s);
+  unsigned long long t0 = 0, r0 = 0;
+  if (S.stamp) {
+    t0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
   seg_call<Body>(g - S.lo[s], S.a[s], std::index_sequence_for<A...>{});
+  if (S.stamp) {  // (a body's early `return` ends the inlined body, not the kernel: every wave gets here)
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+      atomicAdd(S.stamp, t1 - t0);
+      atomicAdd(S.stamp + 1, r1 - r0);
+      atomicAdd(S.stamp + 2, 1ull);
+    }
+  }
 }
 
 // ---- boundary <-> internal I/O --------------------------------------------------
@@ -152,7 +172,7 @@ template <class C> GS_HD void aff_store(uint8_t* p, const Aff<Fp2<C>>& a) {
 // --------------------------------------------------------------------------
 // generic helpers
 // --------------------------------------------------------------------------
-template <class C, class F>
+template <class C, class F, bool ENDO = true>
 __global__ void __launch_bounds__(64, GS_WPE) k_smul_batch(size_t n, const uint8_t* p, int broadcast, const Fr<C>* k,
                                                    uint8_t* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,7 +180,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_smul_batch(size_t n, const uint8
   Aff<F> P;
   aff_load<C>(P, p + (broadcast ? 0 : i) * AFFB(C, F));
   Jac<F> J;
-  jac_smul_any<C>(J, P, from_mont(k[i]));
+  jac_smul_any<C, F, ENDO>(J, P, from_mont(k[i]));
   Aff<F> R;
   jac_to_aff(R, J);
   aff_store<C>(out + i * AFFB(C, F), R);
@@ -489,7 +509,7 @@ __global__ void __launch_bounds__(64, GS_WPE) k_rlc_tpow(size_t N, const uint8_t
 // --------------------------------------------------------------------------
 // linear-combination engine
 // --------------------------------------------------------------------------
-template <class C, class F>
+template <class C, class F, bool ENDO = true>
 struct k_var {
   static __device__ __forceinline__ void run(size_t g, size_t total, int ntask, const VarTask* tasks, ArrTab arrs,
                                             const Fr<C>* pool, int pool_n, Jac<F>* part, int nslots) {
@@ -501,7 +521,7 @@ struct k_var {
   aff_load<C>(P, arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
   if (t.neg) P.y = neg(P.y);
   Jac<F> J;
-  jac_smul_any<C>(J, P, k);
+  jac_smul_any<C, F, ENDO>(J, P, k);
   part[e * nslots + t.slot] = J;
 }
 };
@@ -1068,6 +1088,32 @@ __global__ void __launch_bounds__(64, GS_WPE) k_wire_dec_pts(size_t n, const uin
   Aff<F> p;
   bool good = wire_decode_point<C, F>(p, in + g * wire_point_bytes<C, F>(compressed != 0), compressed != 0, validate != 0);
   aff_store<C>(pts + g * AFFB(C, F), p);
+  ok[g] = good ? 1 : 0;
+}
+// In-memory points (boundary limbs, include/gs_amd.h) through the checks the wire decoder applies to decoded ones:
+// canonical coordinates (every Montgomery word string < p), the identity flag (0, 0), on the curve, and in the r-torsion
+// (the endomorphism tests of gs_wire.cuh).  The reference's plain double-and-add takes ANY curve point
+// (data_structures.rs:336-342); the GLV / psi-GLS scalar multiplications here are only defined on the r-torsion, so a
+// caller that did not get its points from a validating decoder asks this first (or turns the endomorphisms off).
+template <class C, class F>
+__global__ void __launch_bounds__(64, GS_WPE) k_validate_pts(size_t n, const uint8_t* pts, uint8_t* ok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  constexpr int NW = (int)(AFFB(C, F) / (4 * C::N));  // Fq words strings per point: 2 (G1) or 4 (G2)
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(pts + g * AFFB(C, F));
+  bool canon = true, zero = true;
+  for (int k = 0; k < NW; k++) {
+    uint32_t t[C::N];
+    for (int i = 0; i < C::N; i++) t[i] = w[k * C::N + i];
+    canon = canon && words_lt_p<C>(t);
+    zero = zero && words_zero<C::N>(t);
+  }
+  bool good = canon;
+  if (canon && !zero) {
+    Aff<F> p;
+    aff_load<C>(p, pts + g * AFFB(C, F));
+    good = eq(sqr(p.y), curve_rhs<C>(p.x)) && in_prime_subgroup<C>(p);
+  }
   ok[g] = good ? 1 : 0;
 }
 // Fq arrays (GT = 12 per element): dir 0 boundary -> canonical little-endian bytes, dir 1 back (ok = canonical)

@@ -22,7 +22,10 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include <condition_variable>
 #include <functional>
@@ -154,6 +157,18 @@ struct gs_multi {
   std::vector<void*> sendb, recvb;
   bool bufs_ready = false, rccl_ready = false, rccl_failed = false;
   std::string rccl_why;
+  // The pair exchange has three LEGS, tried in this order; a leg that fails at run time is marked failed (with its
+  // reason) and the SAME call goes on with the next one -- it does not return an error while a slower way exists:
+  //   0  RCCL all-gather            (shards on distinct devices, librccl loaded, communicators up)
+  //   1  device / peer copies       (hipMemcpyAsync on one device, hipMemcpyPeerAsync between devices)
+  //   2  host-staged copies         (every pair down to the host, the gathered block up to every shard)
+  bool leg_failed[3] = {false, false, false};
+  std::string leg_why[3];
+  int leg_used = -1;       // what the last exchange ran on
+  int fail_mask = 0;       // test hook ("exchange_fail", GS_MULTI_EXCHANGE_FAIL): bit k makes leg k fail when it runs
+  int first_leg = 0;       // "exchange_leg": start the chain at this leg
+  bool peer_probed = false, peer_ok = true;  // hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess over all shard pairs
+  std::string note;
   size_t gt = 0;
   std::vector<uint8_t> one;  // the GT identity in boundary form (accumulator pair of an empty block)
 };
@@ -191,6 +206,7 @@ template <class F> static int on_all(gs_multi* m, F fn) {
   return GS_OK;
 }
 
+static void probe_peers(gs_multi* m);
 // exchange buffers (always) and, for distinct devices, the RCCL communicators.  A failure to bring RCCL up is
 // remembered with its reason and the exchange falls back to peer copies; a failed buffer allocation is retried by the
 // next call (nothing sticky but what succeeded).
@@ -210,6 +226,7 @@ static int exchange_setup(gs_multi* m) {
     }
     m->bufs_ready = true;
   }
+  probe_peers(m);
   if (nd > 1 && m->distinct && !m->rccl_ready && !m->rccl_failed) {
     m->rccl = load_rccl();
     if (!m->rccl.ok()) {
@@ -230,12 +247,39 @@ static int exchange_setup(gs_multi* m) {
   return GS_OK;
 }
 
-// every shard's pair sits in sendb[i] (its context's stream has been drained): all nd pairs, in shard order, into
-// every recvb[i]
-static int exchange_pairs(gs_multi* m) {
+// peer access between the shards' devices, probed once (gs_ctx_create_multi): hipMemcpyPeerAsync works without it (the
+// runtime stages through the host) but with it the copy is one xGMI transfer; what was found goes into the note
+static void probe_peers(gs_multi* m) {
+  if (m->peer_probed) return;
+  m->peer_probed = true;
+  int nd = (int)m->ctx.size();
+  for (int i = 0; i < nd; i++)
+    for (int j = 0; j < nd; j++) {
+      if (m->devices[i] == m->devices[j]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, m->devices[i], m->devices[j]) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        m->peer_ok = false;
+        continue;
+      }
+      if (hipSetDevice(m->devices[i]) == hipSuccess) {
+        hipError_t e = hipDeviceEnablePeerAccess(m->devices[j], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) m->peer_ok = false;
+        (void)hipGetLastError();
+      }
+    }
+}
+
+static bool leg_applies(const gs_multi* m, int leg) {
+  if (m->leg_failed[leg]) return false;
+  if (leg == 0) return m->rccl_ready || (m->fail_mask & 1);  // (the hook lets a one-GPU box walk the chain from the top)
+  return true;
+}
+static int run_leg(gs_multi* m, int leg) {
   int nd = (int)m->ctx.size();
   const size_t pair = 2 * m->gt;
-  if (m->rccl_ready) {
+  if (m->fail_mask & (1 << leg)) return mfail(m, GS_ERR_DEVICE, "injected failure (exchange_fail)");
+  if (leg == 0) {
     m->rccl.GroupStart();
     for (int i = 0; i < nd; i++) {
       ncclResult_t r = m->rccl.AllGather(m->sendb[i], m->recvb[i], pair, kNcclUint8, m->comms[i], m->cstream[i]);
@@ -245,7 +289,7 @@ static int exchange_pairs(gs_multi* m) {
       }
     }
     if (m->rccl.GroupEnd() != 0) return mfail(m, GS_ERR_DEVICE, "ncclGroupEnd");
-  } else {
+  } else if (leg == 1) {
     for (int i = 0; i < nd; i++) {
       if (hipSetDevice(m->devices[i]) != hipSuccess) return mfail(m, GS_ERR_DEVICE, "hipSetDevice");
       for (int j = 0; j < nd; j++) {
@@ -253,14 +297,59 @@ static int exchange_pairs(gs_multi* m) {
         hipError_t e = m->devices[i] == m->devices[j]
                            ? hipMemcpyAsync(dst, m->sendb[j], pair, hipMemcpyDeviceToDevice, m->cstream[i])
                            : hipMemcpyPeerAsync(dst, m->devices[i], m->sendb[j], m->devices[j], pair, m->cstream[i]);
-        if (e != hipSuccess) return mfail(m, GS_ERR_DEVICE, std::string("pair exchange: ") + hipGetErrorString(e));
+        if (e != hipSuccess) {
+          (void)hipGetLastError();
+          return mfail(m, GS_ERR_DEVICE, std::string("pair exchange (device / peer copy): ") + hipGetErrorString(e));
+        }
       }
     }
+  } else {
+    // host-staged: nd small downloads, nd uploads of the gathered block (nd x 1152 bytes); synchronous copies
+    std::vector<uint8_t> all((size_t)nd * pair);
+    for (int j = 0; j < nd; j++)
+      if (hipSetDevice(m->devices[j]) != hipSuccess ||
+          hipMemcpy(all.data() + (size_t)j * pair, m->sendb[j], pair, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return mfail(m, GS_ERR_DEVICE, "pair exchange (host-staged download)");
+      }
+    for (int i = 0; i < nd; i++)
+      if (hipSetDevice(m->devices[i]) != hipSuccess ||
+          hipMemcpy(m->recvb[i], all.data(), all.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return mfail(m, GS_ERR_DEVICE, "pair exchange (host-staged upload)");
+      }
+    return GS_OK;
   }
   for (int i = 0; i < nd; i++)
-    if (hipSetDevice(m->devices[i]) != hipSuccess || hipStreamSynchronize(m->cstream[i]) != hipSuccess)
-      return mfail(m, GS_ERR_DEVICE, "pair exchange (sync)");
+    if (hipSetDevice(m->devices[i]) != hipSuccess || hipStreamSynchronize(m->cstream[i]) != hipSuccess) {
+      (void)hipGetLastError();
+      return mfail(m, GS_ERR_DEVICE, leg == 0 ? "rccl all-gather (sync)" : "pair exchange (sync)");
+    }
   return GS_OK;
+}
+
+// every shard's pair sits in sendb[i] (its context's stream has been drained): all nd pairs, in shard order, into
+// every recvb[i].  Walks the legs (see gs_multi): a failed leg is remembered and the call retries on the next one.
+static int exchange_pairs(gs_multi* m) {
+  static const char* names[3] = {"rccl all-gather", "device / peer copies", "host-staged copies"};
+  int nd = (int)m->ctx.size();
+  std::string chain;
+  for (int leg = m->first_leg; leg < 3; leg++) {
+    if (!leg_applies(m, leg)) continue;
+    int rc = run_leg(m, leg);
+    if (rc == GS_OK) {
+      m->leg_used = leg;
+      return GS_OK;
+    }
+    m->leg_failed[leg] = true;
+    m->leg_why[leg] = m->err;
+    chain += std::string(names[leg]) + " failed (" + m->err + "); ";
+    // whatever the failed leg left queued must not land in the buffers while the next leg fills them
+    for (int i = 0; i < nd; i++)
+      if (hipSetDevice(m->devices[i]) == hipSuccess && m->cstream[i]) (void)hipStreamSynchronize(m->cstream[i]);
+    (void)hipGetLastError();
+  }
+  return mfail(m, GS_ERR_DEVICE, "pair exchange: every leg failed: " + chain);
 }
 
 // after the shards wrote their pairs: gather, cross-check, one final exponentiation on device 0
@@ -316,6 +405,10 @@ int gs_ctx_create_multi_ex(int curve, const int* devices, int ndev, int flags, g
       m->workers.push_back(new Worker());
       m->workers.back()->start(devices[i]);
     }
+  if (const char* e = getenv("GS_MULTI_EXCHANGE_FAIL")) m->fail_mask = atoi(e) & 7;
+  if (const char* e = getenv("GS_MULTI_EXCHANGE_LEG")) m->first_leg = std::min(2, std::max(0, atoi(e)));
+  probe_peers(m);
+  hipSetDevice(devices[0]);
   *out = m;
   return GS_OK;
 }
@@ -346,14 +439,50 @@ void gs_multi_destroy(gs_multi* m) {
 int gs_multi_ndev(gs_multi* m) { return m ? (int)m->ctx.size() : 0; }
 gs_ctx* gs_multi_ctx(gs_multi* m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[i] : nullptr; }
 const char* gs_multi_last_error(gs_multi* m) { return m ? m->err.c_str() : "null context"; }
-int gs_multi_uses_rccl(gs_multi* m) { return (m && m->rccl_ready) ? 1 : 0; }
+int gs_multi_uses_rccl(gs_multi* m) { return (m && m->rccl_ready && !m->leg_failed[0]) ? 1 : 0; }
 const char* gs_multi_exchange_note(gs_multi* m) {
   if (!m) return "null context";
-  if (m->rccl_ready) return "rccl all-gather";
-  if (m->ctx.size() == 1) return "one shard: device-to-device copy";
-  if (!m->distinct) return "shards share a device: device-to-device copies";
-  if (m->rccl_failed) return m->rccl_why.c_str();
-  return "not set up yet";
+  static const char* names[3] = {"rccl all-gather", "device / peer copies", "host-staged copies"};
+  std::string n;
+  if (m->leg_used >= 0) {
+    n = std::string("last exchange: ") + names[m->leg_used];
+    if (m->leg_used == 1 && m->ctx.size() == 1) n += " (one shard: device-to-device copy)";
+    if (m->leg_used == 1 && m->ctx.size() > 1 && !m->distinct) n += " (shards share a device)";
+  }
+  else if (m->rccl_ready && !m->leg_failed[0])
+    n = "rccl all-gather";
+  else if (m->ctx.size() == 1)
+    n = "one shard: device-to-device copy";
+  else if (!m->distinct)
+    n = "shards share a device: device-to-device copies";
+  else if (m->rccl_failed)
+    n = "device / peer copies (" + m->rccl_why + ")";
+  else
+    n = "not set up yet";
+  for (int k = 0; k < 3; k++)
+    if (m->leg_failed[k]) n += std::string("; ") + names[k] + " failed earlier: " + m->leg_why[k];
+  if (m->peer_probed && m->distinct && m->ctx.size() > 1) n += m->peer_ok ? "; peer access enabled" : "; no peer access between some shards";
+  m->note = n;
+  return m->note.c_str();
+}
+// "exchange_leg" 0..2: the leg the pair exchange starts at (0 = RCCL where it applies); "exchange_fail": bit k makes
+// leg k fail when it runs (test hook for the fallback chain); "exchange_reset" (any value): forget earlier failures
+int gs_multi_set_option(gs_multi* m, const char* key, int value) {
+  if (!m || !key) return GS_ERR_ARG;
+  std::string k(key);
+  if (k == "exchange_leg") {
+    if (value < 0 || value > 2) return mfail(m, GS_ERR_ARG, "exchange_leg: 0 rccl, 1 device / peer copies, 2 host-staged");
+    m->first_leg = value;
+  } else if (k == "exchange_fail") {
+    if (value < 0 || value > 7) return mfail(m, GS_ERR_ARG, "exchange_fail: bit mask of legs 0..2");
+    m->fail_mask = value;
+  } else if (k == "exchange_reset") {
+    for (int i = 0; i < 3; i++) m->leg_failed[i] = false, m->leg_why[i].clear();
+    m->leg_used = -1;
+  } else {
+    return mfail(m, GS_ERR_ARG, "unknown option");
+  }
+  return GS_OK;
 }
 
 int gs_multi_shard(gs_multi* m, size_t N, int i, size_t* lo, size_t* hi) {

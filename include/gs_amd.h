@@ -42,8 +42,11 @@
  * points, and -- UNLIKE the reference, whose plain double-and-add works on any curve
  * point -- results for on-curve points OUTSIDE the subgroups are UNDEFINED here
  * (scalar multiplications use the GLV / psi-GLS endomorphisms, which act as a
- * scalar only on the r-torsion).  Decode untrusted bytes with gs_wire_decode_*
- * (validate = 1) before handing points to the *_dev calls.
+ * scalar only on the r-torsion).  Three ways to be safe: decode untrusted bytes with
+ * gs_wire_decode_* (validate = 1); run in-memory limbs through gs_validate_points[_dev]
+ * (the same canonical / on-curve / r-torsion tests); or gs_set_option("endo", 0), which
+ * runs every variable-base scalar multiplication as plain double-and-add on any curve
+ * point, exactly the reference's tolerance.
  *
  * Errors: the reference panics on shape mismatch (assert_eq!, e.g.
  * src/prover/prove.rs:106-113); here every call returns a status and a shim
@@ -85,6 +88,12 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream
  *   "var_tab"      -1 planned | 0 the verifier's Gamma^T c on Straus lanes with their own tables | 1 on window tables of
  *                   the commitment components shared by all outputs (8-bit windows; what large arities use)
+ *   "endo"          1 (default) GLV / psi-GLS scalar multiplications: r-torsion points only | 0 every variable-base scalar
+ *                   multiplication is a plain signed-window double-and-add lane ("k_var.plain", "k_smul_batch.plain"):
+ *                   defined on ANY curve point, like the reference's Com::scalar_mul (data_structures.rs:336-342), at
+ *                   ~2.5x the variable-base work.  For callers that cannot vouch for subgroup membership and do not want
+ *                   to pay gs_validate_points first.  (This one changes WHICH inputs are supported, not the results on
+ *                   supported ones.)
  *   "mixed_merge"  -1 planned (merged up to 2^14 equations per call on a 256-CU device) | 0 the parts of a mixed call run
  *                   one after the other | 1 their launches are merged
  * The same knobs are read ONCE at gs_ctx_create from the environment for experiments without recompiling the caller:
@@ -106,7 +115,8 @@ int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the
  * hipHostRegister) is staged like pageable memory -- the runtime cannot tell such memory from ranges it has pinned
  * itself for an earlier pageable copy, and those may be mapped read-only or belong to a buffer freed since.
  * Registrations are per process, not per context: they outlive gs_ctx_destroy and end with gs_host_unregister (any live
- * context may be passed).  gs_host_unregister waits for the context's stream first.  GS_ERR_ARG: null / empty / already registered (here or
+ * context may be passed).  gs_host_unregister first drains EVERY live context of the process (compute stream, side
+ * streams and the copy queues -- the shards of a gs_multi context included): no DMA touches the range afterwards.  GS_ERR_ARG: null / empty / already registered (here or
  * elsewhere) / unknown. */
 int gs_host_register(gs_ctx* ctx, void* ptr, size_t bytes);
 int gs_host_unregister(gs_ctx* ctx, void* ptr);
@@ -126,7 +136,7 @@ int gs_sizes(int curve_id, size_t out[6]);
  *     2 x (SIMDs of the device) x 64 lanes per side ("var_ws_lanes" lowers that): <= 9.2 GB for the largest lane
  *     shape (G2, 8 terms, 5-bit windows), ~6 GB in total for the 2^16 PPE shapes;
  *   - host-pointer entry points only: a pinned host buffer and device staging of the call's input + output bytes each
- *     (0.45 GB for a 2^16 PPE prove);
+ *     (a 2^16 PPE 4x4: 0.45 GB for prove, 0.37 GB for verify; grow-only, so a context that does both holds 0.45 GB);
  *   - large arities only: the shared per-base window tables, N x 2 m bases x 128 entries (affine + Jacobian staging:
  *     36 KB per base in G1; planned only while that stays below 8 GB);
  *   - mixed calls: the above once per PART (the parts' scratch is live at the same time).
@@ -162,7 +172,8 @@ int gs_commit_fr_b2(gs_ctx*, size_t count, const void* y_fr, const void* rand_fr
  * staged through a grow-only PINNED buffer by a few memcpy workers, uploaded on a copy stream array by array, and the
  * kernels wait only for the arrays they read (scalars before the preparation kernel, G1 arguments before the G1 side,
  * G2 arguments before the G2 side / the Miller loop), so most of the transfer runs under kernels; outputs come back
- * the same way.  Per context: pinned staging = the call's input + output bytes (0.83 GB at 2^16 PPE 4x4),
+ * the same way.  Per context: pinned staging = the largest call's input + output bytes (2^16 PPE 4x4:
+ * 0.45 GB for prove, 0.37 GB for verify; 0.83 GB is what ONE prove + verify step moves across PCIe, not what is held),
  * device staging the same, plus the engine's scratch (section "memory" of DESIGN.md). */
 int gs_prove_batch_dev(gs_ctx*, int equ_type, size_t N, int m, int n, const void* X, const void* Y, const void* A,
                        const void* B, const void* Gamma, const void* R, const void* S, const void* T, void* xcoms,
@@ -202,10 +213,16 @@ int gs_verify_statement(gs_ctx*, int equ_type, size_t E, int m, int n, const voi
 /* ---- mixed batches and mixed-type Statements: several sub-batches in ONE call ------------------------------------
  * configs[2] of the baseline mixes PPE, MSMEG1 and MSMEG2 equations; the reference's Statement is a list of equations
  * of ANY type over one list of variables (src/statement.rs:24-28,109).  A part is a homogeneous sub-batch (type, N, m,
- * n and the arrays of gs_prove_batch / gs_verify_batch for it); parts may differ in type AND shape.  All parts are in
- * flight together (each on a child context: own stream and scratch, the parent's CRS tables), so a mixed batch fills
- * the chip like a homogeneous batch of its total size; outputs are byte-identical to one gs_prove_batch /
- * gs_verify_batch call per part.
+ * n and the arrays of gs_prove_batch / gs_verify_batch for it); parts may differ in type AND shape.  Outputs are
+ * byte-identical to one gs_prove_batch / gs_verify_batch call per part.  How the parts run ("mixed_merge"):
+ *   - up to 2^14 equations per call (16 x the device's SIMDs): RECORD AND MERGE on the context's own stream.  Every part's
+ *     launches are recorded (nothing is enqueued; the part's scratch buffers carry a per-part tag so that they are live
+ *     side by side), then replayed in step: launches of different parts that run the same kernel body become ONE
+ *     segmented launch (k_seg, up to 4 segments), so a mixed batch of a few thousand equations fills the chip like a
+ *     homogeneous batch of its total size (2^12: 0.92-0.94 of the PPE-only rate);
+ *   - larger calls, a single part, or while the kernel profile is on: the parts run one after the other on the
+ *     context's stream, each with its own lane shapes (every part fills the chip by itself from ~2^15 on).
+ * There are no child contexts or extra streams (measured and rejected: profiles/r3/mixed_streams.txt).
  * shared_vars != 0 makes the part a Statement's: X, Y, R, S hold ONE copy (m / n entries) that all N equations of the
  * part use, xcoms / ycoms are the statement's commitments (m / n entries; prove writes them when non-NULL -- pass them
  * with ONE of the parts that use a variable group and NULL with the others -- verify reads them), i.e. exactly
@@ -289,6 +306,13 @@ gs_ctx* gs_multi_ctx(gs_multi*, int i);                      /* shard i's contex
 const char* gs_multi_last_error(gs_multi*);
 int gs_multi_uses_rccl(gs_multi*);                           /* 1 once the RCCL communicators exist */
 const char* gs_multi_exchange_note(gs_multi*);               /* how the accumulator pairs travel (and why not RCCL) */
+/* The pair exchange walks three legs -- 0 RCCL all-gather, 1 device / peer copies (hipMemcpyPeerAsync; peer access is
+ * probed and enabled at gs_ctx_create_multi), 2 host-staged copies -- and a leg that FAILS AT RUN TIME is marked failed
+ * and the same call retries on the next one (it is not an error while a slower way exists; gs_multi_exchange_note names
+ * the leg used and why earlier ones failed).  Options: "exchange_leg" 0..2 start the chain there; "exchange_fail" bit
+ * mask: leg k fails when it runs (test hook: how the chain is exercised on a one-GPU box; also GS_MULTI_EXCHANGE_FAIL /
+ * GS_MULTI_EXCHANGE_LEG at create); "exchange_reset": forget earlier failures. */
+int gs_multi_set_option(gs_multi*, const char* key, int value);
 int gs_multi_shard(gs_multi*, size_t N, int i, size_t* lo, size_t* hi); /* block [lo, hi) of shard i */
 int gs_multi_set_crs(gs_multi*, const void* crs_host);
 int gs_multi_sync(gs_multi*);                                /* drain every shard's stream */
@@ -361,6 +385,15 @@ int gs_wire_decode_fr(gs_ctx*, size_t n, const uint8_t* in, void* fr, uint8_t* o
 int gs_wire_encode_gt(gs_ctx*, size_t n, const void* gt, uint8_t* out);
 int gs_wire_decode_gt(gs_ctx*, size_t n, int validate, const uint8_t* in, void* gt, uint8_t* ok);
 
+/* ---- subgroup safety for in-memory points (the wire decoder's tests without the wire format) ----------------------
+ * ok[i] = 1 iff point i of pts (G1: group = 1, G2: group = 2; boundary limbs as everywhere) has canonical coordinates
+ * (every word string < p), is the identity (0, 0) or lies on the curve, AND is in the prime-order subgroup (BLS12-381:
+ * the endomorphism tests arkworks uses; BN254 G1: cofactor 1, G2: [r]Q = O).  The reference needs no such call: its
+ * double-and-add takes any curve point (src/data_structures.rs:336-342) and arkworks' deserialisation has validated
+ * everything it holds. */
+int gs_validate_points_dev(gs_ctx*, int group, size_t n, const void* pts_dev, uint8_t* ok_dev);
+int gs_validate_points(gs_ctx*, int group, size_t n, const void* pts, uint8_t* ok);
+
 /* ---- measurement hook ----------------------------------------------------
  * Name and average duration (ms, HIP events on the context's stream) of the
  * kernels launched since gs_prof_reset; used by bench.py for the roofline. */
@@ -370,6 +403,10 @@ int gs_prof_get(gs_ctx*, int idx, char* name, size_t name_cap, double* total_ms,
 /* lane-tasks launched under that name and its kernel-specific work items (fixed-base scalars for k_fix, terms for
  * k_var_multi, partial sums for k_red, pairs for k_miller, lanes otherwise): inputs of bench.py's ALU roofline */
 int gs_prof_get_work(gs_ctx*, int idx, uint64_t* lanes, uint64_t* work);
+/* the clock (GHz) the launches under entry idx ran at, measured INSIDE them: every wave of a segmented launch stamps
+ * s_memtime (shader cycles) and s_memrealtime (100 MHz) around its body while the profile is on; 0 where unavailable.
+ * bench.py prices the multiply-add issue peak at this clock (one measurement: no separate clock correction). */
+int gs_prof_get_clock(gs_ctx*, int idx, double* ghz);
 
 #ifdef __cplusplus
 }

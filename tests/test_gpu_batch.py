@@ -105,8 +105,11 @@ def test_bench_two_rank_rehearsal(mode, launch):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "strong"
-    assert line["config"]["total_equations"] == 512
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["total_equations"] == 512 and line["config"]["collective_backend"] == "gloo"
+    assert line["config"]["rccl_ranks"] == 0 and line["config"]["distinct_devices"] == 1  # a rehearsal, and it says so
+    if mode == "exact":
+        assert line["config"]["rank_combined_check"] == {"corrupted_on_rank": 1, "failures_seen_by_every_rank": 4}
     assert line["value"] == pytest.approx(2 * 256 / (line["ms_per_step"] / 1e3), rel=1e-6)
     assert line["roofline"]["alu"]["frac"] > 0
 
@@ -127,8 +130,47 @@ def test_bench_inproc_rehearsal():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["shards"] == 3 and line["config"]["devices"] == [0, 0, 0]
-    assert line["config"]["total_equations"] == 768 and line["scaling"] == "strong"
+    assert line["config"]["total_equations"] == 768 and line["scaling"] == "weak"
     assert line["value"] == pytest.approx(768 / (line["ms_per_step"] / 1e3), rel=1e-6)
+
+
+def test_bench_driver_line_rehearsal_four_ranks_and_eight_shards():
+    """The driver's multi-GPU line, rehearsed as far as a one-GPU box allows.
+      * `bench.py --gpus 4 --steps 2 --warmup 1` under gloo with the ranks sharing cuda:0 (the box admits at most six
+        processes on its GPU -- this test process is one of them -- so the 8-rank line itself cannot be started here: a
+        6-rank attempt was killed by the box's process guard; four ranks walk the same code: per-rank
+        seeds and blocks, barrier + max-over-ranks timing, the failure-count all-reduce inside every timed step, the
+        rank-combined verdict with corrupted proofs on the LAST rank only, cpu_baseline on rank 0);
+      * `bench.py --gpus 8 --inproc` with EIGHT shards of 2^15 equations on the one GPU: 2^18 equations in all
+        (configs[3]) through gs_ctx_create_multi and the device-pointer family, corrupted proofs found in every shard
+        (asserted inside bench.py)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, GS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--log2n", "10",
+           "--cpu-sample", "32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["total_equations"] == 4 * 1024 and line["config"]["equations_per_gpu"] == 1024
+    assert line["config"]["rank_combined_check"]["corrupted_on_rank"] == 3
+    assert line["config"]["rank_combined_check"]["failures_seen_by_every_rank"] == 4
+    assert line["config"]["distinct_devices"] == 1 and line["config"]["rccl_ranks"] == 0
+    assert line["cpu_baseline"]["value"] > 0  # N > 1 lines carry the CPU baseline too (rank 0's host cores)
+    assert line["value"] == pytest.approx(4 * 1024 / (line["ms_per_step"] / 1e3), rel=1e-6)
+
+    env = dict(os.environ, GS_BENCH_SHARED="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--inproc", "--steps", "2", "--warmup", "1",
+           "--log2n", "15"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["config"]["shards"] == 8 and line["config"]["total_equations"] == 1 << 18 and line["n_gpus"] == 1
+    assert line["value"] == pytest.approx((1 << 18) / (line["ms_per_step"] / 1e3), rel=1e-6)
 
 
 def test_bench_refuses_fewer_ranks_than_requested():

@@ -3,8 +3,9 @@
   * configs[2] of the baseline: a batch that mixes PPE, MSMEG1 and MSMEG2 equations (here also of different shapes)
     proved and verified in one call -- the parts' launches recorded and MERGED into segmented launches (k_seg: one
     launch per kernel body with a segment per part) -- gives byte-for-byte what one gs_prove_batch / gs_verify_batch
-    call per sub-batch gives, through host pointers and through device pointers, and with the library's kernel
-    profile on (parts one after the other: the kernel names of a merged launch must show in the profile-free run);
+    call per sub-batch gives, through host pointers and through device pointers, merged and (mixed_merge = 0) with the
+    parts one after the other, and with the library's kernel profile on (it times the MERGED launches themselves:
+    round 4 -- the per-kernel times of a mixed step then add up to the step bench.py times);
   * a mixed-type STATEMENT (statement.rs:24-28,109: equations of any type over ONE list of variables): the variables are
     committed once per group, 70 equations of the four types (two waves of PPEs) get their proofs in one call, and EVERY
     equation's pi / theta and the shared commitments equal the C oracle's commit_and_prove with the same X, Y, R, S and
@@ -44,9 +45,14 @@ def test_mixed_batch_equals_one_call_per_sub_batch():
         want.append({k: host(getattr(wl, k)) for k in OUT_P})
         hostin.append({k: host(getattr(wl, k)) for k in IN_P + ("target",)})
     parts = [dict(ty=ty, N=N, m=m, n=n, **{k: h[k] for k in IN_P}) for (ty, N, m, n), h in zip(shapes, hostin)]
-    for prof in (False, True):  # merged segmented launches / one part after the other under the kernel profile
+    for prof, merge in ((False, 1), (True, 1), (False, 0)):  # merged launches, the same under the profile, in sequence
         eng.prof_enable(prof)
+        eng.prof_reset()
+        eng.set_option("mixed_merge", merge)
         got = eng.prove_mixed(parts)
+        if prof:  # the profile saw the merged launches: ONE k_prep_prove launch for the four parts, not four
+            launches = {n: k for n, _, k in eng.prof_get()}
+            assert launches.get("k_prep_prove") == 1, launches
         for g, w in zip(got, want):
             for k in OUT_P:
                 assert (g[k] == w[k]).all(), (k, prof)
@@ -59,6 +65,7 @@ def test_mixed_batch_equals_one_call_per_sub_batch():
         oks = eng.verify_mixed(vparts)
         assert oks[0].all() and oks[1].all() and oks[3].all() and oks[2][:69].all() and oks[2][69] == 0
     eng.prof_enable(False)
+    eng.set_option("mixed_merge", -1)
     # six parts in one call: more parts than a merged launch has segments (4), so every body goes out in two launches
     got6 = eng.prove_mixed((parts * 2)[:6])
     for g, w in zip(got6, (want * 2)[:6]):

@@ -155,6 +155,59 @@ def test_split_over_several_shards_of_one_gpu(cname, cid, ndev, N):
         eng.close()
 
 
+def test_pair_exchange_fallback_chain():
+    """The accumulator-pair exchange of the batched verifier walks three legs (RCCL all-gather, device / peer copies,
+    host-staged copies); a leg that fails AT RUN TIME is marked failed and the same call retries on the next one
+    (the first 8-GPU run must not die on a failed collective).  Each failure is injected
+    ("exchange_fail" bit k: leg k fails when it runs) on three shards of the one GPU: same verdicts and the same
+    gathered pairs on every leg, the note names the leg used and why the earlier ones failed, a failed leg is not
+    tried again, a corrupted proof is still found, and only when EVERY leg fails does the call return an error."""
+    import groth_sahai_rs_amd as gs
+    from groth_sahai_rs_amd.workload import Workload
+
+    N, m, n, ty, nd = 19, 2, 3, 0, 3
+    eng = gs.Engine(0, 0)
+    wl = Workload(eng, ty=ty, N=N, m=m, n=n, seed=8950, corrupt_every=0)
+    wl.prove()
+    eng.sync()
+    host = lambda t: t.cpu().numpy()
+    A, B, G, tgt, xc, yc, pi, th = [host(getattr(wl, k)) for k in ("A", "B", "Gamma", "target", "xcoms", "ycoms", "pi", "theta")]
+    rho = np.frombuffer(np.random.default_rng(77).bytes(N * 32), dtype=np.uint64) | np.uint64(1)
+    bad = pi.copy()
+    bad[(N - 1) * (len(bad) // N) + 9] ^= 8
+    me = gs.MultiEngine(0, [0] * nd, shared_devices=True)
+    me.set_crs(wl.crs)
+    v, want = me.verify_batch_rlc(ty, N, m, n, A, B, G, tgt, xc, yc, pi, th, rho)
+    assert v == 1 and "device / peer copies" in me.exchange_note() and "share a device" in me.exchange_note()
+    for mask, leg, failed in ((1, "device / peer copies", ["rccl all-gather"]),
+                              (3, "host-staged copies", ["rccl all-gather", "device / peer copies"]),
+                              (2, "host-staged copies", ["device / peer copies"])):
+        me.set_option("exchange_reset", 1)
+        me.set_option("exchange_fail", mask)
+        v, pairs = me.verify_batch_rlc(ty, N, m, n, A, B, G, tgt, xc, yc, pi, th, rho)
+        note = me.exchange_note()
+        assert v == 1 and (pairs == want).all(), (mask, note)
+        assert "last exchange: " + leg in note, note
+        for f in failed:
+            assert f + " failed earlier: injected failure" in note, note
+        # sticky: with the hook off again the failed legs stay out of the chain (no retry of a leg that has failed)
+        me.set_option("exchange_fail", 0)
+        v, pairs = me.verify_batch_rlc(ty, N, m, n, A, B, G, tgt, xc, yc, bad, th, rho)
+        assert v == 0 and "last exchange: " + leg in me.exchange_note()
+    me.set_option("exchange_reset", 1)
+    me.set_option("exchange_fail", 7)
+    with pytest.raises(gs.GsError) as ei:
+        me.verify_batch_rlc(ty, N, m, n, A, B, G, tgt, xc, yc, pi, th, rho)
+    assert ei.value.code == 2 and "every leg failed" in str(ei.value)
+    me.set_option("exchange_reset", 1)
+    me.set_option("exchange_fail", 0)
+    me.set_option("exchange_leg", 2)  # start at the host-staged leg
+    v, pairs = me.verify_batch_rlc(ty, N, m, n, A, B, G, tgt, xc, yc, pi, th, rho)
+    assert v == 1 and (pairs == want).all() and "last exchange: host-staged copies" in me.exchange_note()
+    me.close()
+    eng.close()
+
+
 def test_multi_rlc_rejects_null_rho():
     import ctypes
 
