@@ -424,7 +424,7 @@ class Bench:
         torch.cuda.empty_cache()
         return res
 
-    def run_hostptr(self, log2n, steps=3, m=4, n=4):
+    def run_hostptr(self, log2n, steps=3, m=4, n=4, registered=False):
         """The same PPE workload through the HOST-pointer entry points (gs_prove_batch + gs_verify_batch: what a Rust
         caller of prove.rs:29-52 / verifier.rs:18-21 holds): pageable numpy arrays in, arrays out, PCIe inside the
         timed region; next to it the device-resident rate of the same batch on the same box."""
@@ -436,15 +436,24 @@ class Bench:
         eng = self.engine(0)
         N = 1 << log2n
         wl = Workload(eng, ty=0, N=N, m=m, n=n, seed=20241220 + 7, device=self.dev, corrupt_every=0)
-        host = lambda t: t.cpu().numpy()
+        if registered:  # every array in gs_host_alloc memory (pre-faulted, page-locked, registered): DMA-direct
+            def host(t):
+                a = t.cpu().numpy()
+                b = eng.host_alloc(a.nbytes)
+                b[:] = a.reshape(-1).view(np.uint8)
+                return b
+            zeros = lambda k: eng.host_alloc(k)
+        else:
+            host = lambda t: t.cpu().numpy()
+            zeros = lambda k: np.zeros(k, dtype=np.uint8)
         X, Y, A, B, G, R, S, T, tgt = [host(getattr(wl, k)) for k in ("X", "Y", "A", "B", "Gamma", "R", "S", "T", "target")]
 
         # the caller keeps its result buffers from call to call, as a Rust caller reusing its Vecs does (arrays made
         # per call are first touched inside the call: ~30 ms of page faults at 2^16, profiles/r3/hostpipe/)
         sh = eng.shape(0)
-        o = {"xcoms": np.zeros(N * m * eng.COM1, dtype=np.uint8), "ycoms": np.zeros(N * n * eng.COM2, dtype=np.uint8),
-             "pi": np.zeros(N * sh["kx"] * eng.COM2, dtype=np.uint8), "theta": np.zeros(N * sh["ky"] * eng.COM1, dtype=np.uint8)}
-        okbuf = np.zeros(N, dtype=np.uint8)
+        o = {"xcoms": zeros(N * m * eng.COM1), "ycoms": zeros(N * n * eng.COM2),
+             "pi": zeros(N * sh["kx"] * eng.COM2), "theta": zeros(N * sh["ky"] * eng.COM1)}
+        okbuf = zeros(N)
 
         def host_step():
             eng.prove_batch(0, N, m, n, X, Y, A, B, G, R, S, T, out=o)
@@ -468,18 +477,23 @@ class Bench:
             wl.step()
         eng.sync()
         dt_d = (time.perf_counter() - t0) / steps
-        assert okbuf.all() and wl.ok.cpu().numpy().all() and (o["pi"] == host(wl.pi)).all()
+        assert okbuf.all() and wl.ok.cpu().numpy().all() and (o["pi"] == wl.pi.cpu().numpy()).all()
         # (the same arrays page-locked once with gs_host_register -- DMA straight from / to them -- are measured by
         # tools/host_path_rate.py, profiles/r3/host_path_rate.txt: 0.97 at 2^16; not repeated on every bench run)
         nbytes = sum(a.nbytes for a in (X, Y, A, B, G, R, S, T, tgt)) + sum(v.nbytes for v in o.values()) * 2 + \
             A.nbytes + B.nbytes + G.nbytes + N
         del wl
+        if registered:
+            for a in [X, Y, A, B, G, R, S, T, tgt, okbuf] + list(o.values()):
+                eng.host_free(a)
         torch.cuda.empty_cache()
         return {"value": N / dt_h, "ms_per_step": dt_h * 1e3, "steps": steps,
                 "device_resident_value": N / dt_d, "device_resident_ms_per_step": dt_d * 1e3,
                 "ratio_to_device_resident": dt_d / dt_h, "pcie_bytes_per_step": int(nbytes),
-                "workload": "2^%d PPE m=%d n=%d BLS12-381 through gs_prove_batch + gs_verify_batch (pageable host arrays "
-                            "in, result arrays the caller keeps; pinned staging pipeline inside the library)" % (log2n, m, n)}
+                "workload": "2^%d PPE m=%d n=%d BLS12-381 through gs_prove_batch + gs_verify_batch (%s)" % (
+                    log2n, m, n, "every array in gs_host_alloc memory: pre-faulted, page-locked, registered -- DMA "
+                    "straight from / to the caller's buffers" if registered else
+                    "pageable host arrays in, result arrays the caller keeps; pinned staging pipeline inside the library")}
 
     def describe(self, log2n, curve, ty, mixed, mode, m, n):
         return "2^%d independent %s equations per GPU, m=%d n=%d, %s, commit_and_prove+verify(%s)" % (
@@ -723,6 +737,8 @@ def main():
                              "alu_clock_ghz": (rf.get("alu") or {}).get("clock_ghz")}
             also["2p16_ppe_hostptr"] = b.run_hostptr(16, steps=3)
             also["2p12_ppe_hostptr"] = b.run_hostptr(12, steps=20)
+            also["2p16_ppe_hostreg"] = b.run_hostptr(16, steps=3, registered=True)
+            also["2p12_ppe_hostreg"] = b.run_hostptr(12, steps=20, registered=True)
             res["also"] = also
         if not args.no_cpu:  # rank 0 times the CPU baseline on the host cores it is granted, at every N
             threads, _ = host_cores()

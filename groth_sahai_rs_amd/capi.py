@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # every symbol include/gs_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "gs_ctx_create", "gs_ctx_destroy", "gs_set_stream", "gs_set_option", "gs_sync", "gs_host_register",
+    "gs_host_alloc", "gs_host_free",
     "gs_host_unregister", "gs_last_error", "gs_version", "gs_sizes",
     "gs_set_crs", "gs_crs_generate", "gs_crs_generate_hiding",
     "gs_commit_g1_dev", "gs_commit_g2_dev", "gs_commit_fr_b1_dev", "gs_commit_fr_b2_dev",
@@ -139,6 +140,12 @@ class Engine:
             # registrations are process-wide and outlive the context: release what THIS engine registered while the
             # arrays are still alive (a stale start -> bytes entry would make a later array that lands on the same
             # addresses pass for page-locked and be moved by DMA against a dead registration)
+            for addr in list(getattr(self, "_allocs", {})):
+                try:
+                    self.lib.gs_host_free(self.ctx, ctypes.c_void_p(addr))
+                except Exception:
+                    pass
+                self._allocs.pop(addr, None)
             for addr in list(getattr(self, "_registered", {})):
                 try:
                     self.lib.gs_host_unregister(self.ctx, ctypes.c_void_p(addr))
@@ -173,6 +180,23 @@ class Engine:
         import mmap
 
         return np.frombuffer(mmap.mmap(-1, max(int(nbytes), 1)), dtype=np.uint8)[:nbytes]
+
+    def host_alloc(self, nbytes):
+        """A uint8 array over gs_host_alloc memory: pre-faulted, page-locked, registered (DMA-direct in every
+        host-pointer call).  Freed by host_free / close."""
+        ptr = ctypes.c_void_p()
+        self._chk(self.lib.gs_host_alloc(self.ctx, ctypes.c_size_t(max(int(nbytes), 1)), ctypes.byref(ptr)))
+        buf = (ctypes.c_uint8 * max(int(nbytes), 1)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=np.uint8)[:nbytes]
+        if not hasattr(self, "_allocs"):
+            self._allocs = {}
+        self._allocs[ptr.value] = arr
+        return arr
+
+    def host_free(self, arr):
+        addr = arr.ctypes.data
+        self._chk(self.lib.gs_host_free(self.ctx, ctypes.c_void_p(addr)))
+        getattr(self, "_allocs", {}).pop(addr, None)
 
     def host_register(self, arr):
         """Page-lock a numpy array the caller reuses across host-pointer calls (gs_host_register): the pipeline then

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <dlfcn.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -21,6 +22,7 @@
 #include <queue>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -123,6 +125,7 @@ struct gs_ctx {
   // variable-base scalar multiplication is a plain signed-window double-and-add lane (k_var.plain): ANY curve point,
   // like the reference's Com::scalar_mul (data_structures.rs:336-342), ~2.5x the variable-base work
   bool endo = true;
+  int var_w2 = -1;  // G1 Straus lanes in the kernels built for two waves per SIMD: -1 planned, 0 never, 1 always
   int var_tab = -1;      // verifier's Gamma^T c on shared per-base window tables: -1 planned (large arities), 0, 1
   int mixed_merge = -1;  // -1 planned (merge while the parts cannot fill the chip on their own), 0 never, 1 always
   int scratch_tag = 0;
@@ -678,6 +681,23 @@ static std::vector<double> miller_budgets(const gs_ctx* c, bool twin) {
 // (simd_slots x 64 lanes each) keep the launch overhead below 1 % and bound the workspace at 9.2 GB for the largest
 // lane whatever the batch.
 static inline size_t var_ws_default(const gs_ctx* c) { return 2 * c->simd_slots * 64; }
+// Straus lanes per launch.  Two rounds of resident waves is what a 2^16 batch needs; a larger batch used to run as several
+// launches over that workspace, and every launch boundary idles the SIMDs whose last wave finished early (2^17 / 2^18 on
+// one GPU ran 5 % below the 2^16 rate: profiles/r3/bench_log2n17/18.json).  This GPU has 288 GB: when a quarter of
+// the free device memory (at most 32 GB) holds the workspace of more lanes, the launch takes them -- whole rounds of
+// waves, so that a remaining chunk is never a sliver.
+static size_t var_ws_auto(const gs_ctx* c, size_t tot, size_t bytes_per_lane) {
+  const size_t round = c->simd_slots * 64, base = var_ws_default(c);
+  if (tot <= base) return tot;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return base;
+  }
+  size_t budget = std::min(free_b / 4, (size_t)32 << 30);
+  size_t lanes = budget / std::max(bytes_per_lane, (size_t)1) / round * round;
+  return std::min(tot, std::max(lanes, base));
+}
 // launch wrapper with optional HIP-event timing (used by bench.py's roofline leg)
 template <class K, class... Args>
 static int launch(gs_ctx* c, const char* name, K kern, size_t total, int block, Args... args) {
@@ -1337,18 +1357,37 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
     // share_tables; the 4- or 8-term instance follows the part's own group size -- the 8-term one runs 4-term groups
     // too, but 1.8x slower (2^12 mixed: 5.6 against 3.1 ms), so parts are not forced onto it)
     const int tmax = sp.tm > 4 ? 8 : 4;
-    const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes : var_ws_default(c));
+    const size_t lane_ws = ((size_t)tmax << (sp.w - 1)) * (sizeof(Aff<F>) + sizeof(Jac<F>));
+    // (the buffer is grow-only: a workspace that already holds more lanes is used as it is)
+    size_t have = 0;
+    {
+      auto it = c->scratch.find((c->scratch_tag ? "m" + std::to_string(c->scratch_tag) + ":" : std::string()) + t + ".tabws");
+      if (it != c->scratch.end()) have = it->second.cap / lane_ws;
+    }
+    const size_t chunk = std::min(tot, c->var_ws_lanes > 0 ? (size_t)c->var_ws_lanes
+                                                            : std::max(std::min(have, tot), var_ws_auto(c, tot, lane_ws)));
     void* tabws;
-    RC(scratch(c, (t + ".tabws").c_str(), chunk * ((size_t)tmax << (sp.w - 1)) * (sizeof(Aff<F>) + sizeof(Jac<F>)), &tabws));
+    RC(scratch(c, (t + ".tabws").c_str(), chunk * lane_ws, &tabws));
     // kernel name: k_var_multi<TMAX>[w5][x<outputs per lane>]
     std::string kn = std::string("k_var_multi") + (tmax == 4 ? "4" : "8") + (sp.w == 5 ? "w5" : "") +
                      (sp.mo > 1 ? "x" + std::to_string(sp.mo) : "") + tag;
     for (size_t g0 = 0; g0 < tot; g0 += chunk) {
       size_t n = std::min(chunk, tot - g0);
       c->work_hint = (uint64_t)((double)N * sp.var.size() * ((double)n / (double)tot));  // terms
+      // G1 lanes in the two-waves-per-SIMD build when the launch puts (nearly) two waves on every SIMD: fewer, and the
+      // dispatcher doubles waves up on some SIMDs while others idle (measured in round 2: 27 ms instead of 17.7)
+      const bool w2 = std::is_same<F, Fq<C>>::value &&
+                      (c->var_w2 == 1 || (c->var_w2 < 0 && !c->rec && (double)n / 64.0 >= 1.75 * (double)c->simd_slots));
 #define GS_VM(TM, WW)                                                                                                \
-  RC((launch_seg<k_var_multi<C, F, TM, WW>>(c, kn.c_str(), n, 64, tot, (int)sp.grp.size(), dgrp, dvar, arrs, pool, pool_n, \
-                                            (Jac<F>*)part, sp.nslots, g0, (Aff<F>*)tabws)))
+  do {                                                                                                               \
+    if (w2)                                                                                                          \
+      RC((launch_seg<k_var_multi<C, F, TM, WW, (std::is_same<F, Fq<C>>::value ? 2 : 1)>>(                            \
+          c, kn.c_str(), n, 64, tot, (int)sp.grp.size(), dgrp, dvar, arrs, pool, pool_n, (Jac<F>*)part, sp.nslots, g0, \
+          (Aff<F>*)tabws)));                                                                                         \
+    else                                                                                                             \
+      RC((launch_seg<k_var_multi<C, F, TM, WW>>(c, kn.c_str(), n, 64, tot, (int)sp.grp.size(), dgrp, dvar, arrs, pool, \
+                                                pool_n, (Jac<F>*)part, sp.nslots, g0, (Aff<F>*)tabws)));              \
+  } while (0)
       if (tmax == 4 && sp.w == 5)
         GS_VM(4, 5);
       else if (tmax == 4)
@@ -2542,6 +2581,9 @@ int gs_set_option(gs_ctx* c, const char* key, int value) {
   } else if (k == "var_tab") {
     if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "var_tab: -1 (planned), 0 Straus lanes, 1 shared per-base window tables");
     c->var_tab = value;
+  } else if (k == "var_w2") {
+    if (value < -1 || value > 1) return fail(c, GS_ERR_ARG, "var_w2: -1 (planned), 0 one wave per SIMD, 1 two (G1 Straus lanes)");
+    c->var_w2 = value;
   } else if (k == "endo") {
     c->endo = value != 0;
   } else if (k == "mixed_merge") {
@@ -2624,6 +2666,47 @@ int gs_host_unregister(gs_ctx* c, void* ptr) {
     return fail(c, GS_ERR_ARG, "hipHostUnregister", e);
   }
   return GS_OK;
+}
+
+// Buffers for a caller that wants the fast path without thinking about it: a mapping of its own
+// (anonymous mmap: page-aligned, never part of the allocator's heap, so no stale runtime pin can alias it), every page
+// touched up front (MAP_POPULATE: no first-touch faults inside a call -- 27-35 ms at 2^16 for result arrays made per
+// call), page-locked and entered in the registry: arrays inside it go by DMA straight from / to the caller's memory.
+static std::mutex g_alloc_mu;
+static std::map<void*, size_t> g_alloc;  // gs_host_alloc: start -> mapped bytes
+int gs_host_alloc(gs_ctx* c, size_t bytes, void** out) {
+  RC(check_ctx(c, false));
+  if (!out || !bytes) return GS_ERR_ARG;
+  *out = nullptr;
+  const size_t page = 4096, len = (bytes + page - 1) / page * page;
+  void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_POPULATE, -1, 0);
+  if (p == MAP_FAILED) return fail(c, GS_ERR_ALLOC, "gs_host_alloc: mmap");
+  int rc = gs_host_register(c, p, len);
+  if (rc != GS_OK) {
+    munmap(p, len);
+    return rc;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_alloc[p] = len;
+  }
+  *out = p;
+  return GS_OK;
+}
+int gs_host_free(gs_ctx* c, void* ptr) {
+  RC(check_ctx(c, false));
+  if (!ptr) return GS_ERR_ARG;
+  size_t len = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    auto it = g_alloc.find(ptr);
+    if (it == g_alloc.end()) return fail(c, GS_ERR_ARG, "gs_host_free: not a gs_host_alloc buffer");
+    len = it->second;
+    g_alloc.erase(it);
+  }
+  int rc = gs_host_unregister(c, ptr);  // drains every context first
+  munmap(ptr, len);
+  return rc;
 }
 
 int gs_set_crs(gs_ctx* c, const void* crs) {

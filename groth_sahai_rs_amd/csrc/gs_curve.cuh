@@ -172,6 +172,36 @@ template <class C> GS_HD void jac_madd_ip(Jac<Fq<C>>& r, const Aff<Fq<C>>& q) {
     r = tr;
   }
 }
+#if defined(GS_POINT_ASM_G2)
+// G2: the same, the subroutines park what does not fit 256 VGPRs in AGPRs themselves (gen_pointops_asm.py, Prog2).
+// MEASURED AND NOT SHIPPED (round 4, gpurun_out r4e / r4f on 2^16 PPE): bit-exact on every forced shape, but
+// k_var_multi8w5x2.g2 40.0 -> 41.5 ms and k_fix.g2 12.2 -> 17.8 ms.  The straight-line G2 addition is 114 KB of code
+// and the doubling 68 KB -- against a 64 KB instruction cache shared by two CUs -- while hipcc's version keeps
+// calling the SAME 10.6 KB Fp2 multiplier: fewer instructions (14.2 k against ~17 k per addition) lose to instruction
+// fetch.  The G1 pair (42 + 26 KB) stays on the winning side (-11..13 %).  -DGS_POINT_ASM_G2 brings this back.
+template <class C> GS_HD void jac_dbl_ip(Jac<Fp2<C>>& r) {
+  if constexpr (C::L == 14)
+    g2_dbl_call_14<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v);
+  else
+    g2_dbl_call_10<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v);
+}
+template <class C> GS_HD void jac_madd_ip(Jac<Fp2<C>>& r, const Aff<Fp2<C>>& q) {
+  const Jac<Fp2<C>> p0 = r;
+  Aff<Fp2<C>> qq = q;
+  const bool edge = aff_is_inf(q) || is_zero_limbs(r.z);
+  int32_t h[4];
+  if constexpr (C::L == 14)
+    g2_madd_call_14<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v, qq.x.c0.v, qq.x.c1.v, qq.y.c0.v, qq.y.c1.v, h);
+  else
+    g2_madd_call_10<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v, qq.x.c0.v, qq.x.c1.v, qq.y.c0.v, qq.y.c1.v, h);
+  if (edge || (maybe_zero_limbs01<C>(h[0], h[1]) && maybe_zero_limbs01<C>(h[2], h[3]))) {
+    Jac<Fp2<C>> tp = p0, tr;
+    Aff<Fp2<C>> tq = q;
+    jac_madd_edge(tr, tp, tq);
+    r = tr;
+  }
+}
+#endif
 #endif
 
 template <class F> GS_HD void jac_neg(Jac<F>& r, const Jac<F>& p) {
@@ -364,14 +394,22 @@ template <int NL, int W> GS_HD void recode_w_limbs(int8_t* dg, const uint32_t* k
   }
 }
 // tab[i] = (i + 1) P, i = 0 .. NE-1 (k even: 2 (k/2)P; k odd: (k-1)P + P)
+// The chain runs on a value held in registers and updated in place (the G1 / G2 register-only subroutines on the
+// device): an odd multiple continues from the entry just produced, an even one reloads (k/2) P.
 template <class F> GS_HD_NOINLINE void smul_build_table_n(Jac<F>* tab, const Aff<F>& p, int ne) {
-  jac_from_aff(tab[0], p);
+  Jac<F> cur;
+  jac_from_aff(cur, p);
+  tab[0] = cur;
 #pragma unroll 1
   for (int k = 2; k <= ne; k++) {
-    if (k & 1)
-      jac_madd(tab[k - 1], tab[k - 2], p);
-    else
-      jac_dbl(tab[k - 1], tab[k / 2 - 1]);
+    if (k & 1) {
+      jac_madd_ip(cur, p);  // (k - 1) P is what the previous step left in `cur`
+    } else {
+      Jac<F> t = tab[k / 2 - 1];
+      cur = t;
+      jac_dbl_ip(cur);
+    }
+    tab[k - 1] = cur;
   }
 }
 
@@ -705,7 +743,10 @@ GS_STRAUS void jac_straus_build(Aff<F>* at, F& zback, const Aff<F>* ps, int nt, 
 // `tabs` (optional): per-term table pointers instead of the lane's own contiguous `at` -- window tables of the BASES
 // that many lanes share (k_var_tab: one table per (equation, base), true affine entries, zback = 1); `negm` bit t
 // then stands for "-P_t".
-template <class C, class F, int TMAX, int W>
+// GTAB: the tables (`at` / `tabs`) are GLOBAL memory (the kernels' lane-contiguous workspaces, the shared base tables):
+// their look-ups are global_load; false (the single-call helper's local staging) keeps generic loads.
+// LDSKB: LDS a wave may take for its digits (36 KB at one wave per SIMD, 18 KB in kernels built for two).
+template <class C, class F, int TMAX, int W, bool GTAB = false, int LDSKB = 36>
 GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F>* at, const F& zback,
                                    const Aff<F>* const* tabs = nullptr, uint32_t negm = 0) {
   constexpr int NE = 1 << (W - 1);
@@ -725,7 +766,7 @@ GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F
     constexpr int NSL = E::NS * ND;                       // digits per term
     constexpr int ROWB = ((TMAX * NSL + 3) / 4 * 4);      // bytes per lane, whole dwords ...
     constexpr int ROW = ((ROWB / 4) % 2 == 0) ? ROWB + 4 : ROWB;  // ... an ODD number of them
-    constexpr bool LDS_DG = (size_t)ROW * 64 <= 36 * 1024;  // (BN254 G2 with 8 terms does not fit: private frame)
+    constexpr bool LDS_DG = (size_t)ROW * 64 <= (size_t)LDSKB * 1024;  // (else: private frame, as rounds 1-3 had them)
     __shared__ int8_t sdg[LDS_DG ? ROW * 64 : 4];
     int8_t ldg[LDS_DG ? 1 : TMAX * NSL];
     int8_t* const dgp = LDS_DG ? &sdg[(threadIdx.x & 63) * ROW] : ldg;
@@ -757,12 +798,18 @@ GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F
     auto ldaff = [](const Aff<F>* p) -> Aff<F> {
       Aff<F> v;
       constexpr int NWD = (int)(sizeof(Aff<F>) / sizeof(limb_t));
-      // the tables are global memory: global_load, which counts on vmcnt only -- a FLAT load also counts on lgkmcnt,
-      // and the next digit read from LDS (s_waitcnt lgkmcnt(0)) would then wait for the whole prefetch
-      typedef const __attribute__((address_space(1))) limb_t* gptr;
-      gptr w = (gptr) reinterpret_cast<const limb_t*>(p);
+      if constexpr (GTAB) {
+        // global memory: global_load, which counts on vmcnt only -- a FLAT load also counts on lgkmcnt, and the next
+        // digit read from LDS (s_waitcnt lgkmcnt(0)) would then wait for the whole prefetch
+        typedef const __attribute__((address_space(1))) limb_t* gptr;
+        gptr w = (gptr) reinterpret_cast<const limb_t*>(p);
 #pragma unroll
-      for (int q = 0; q < NWD; q++) reinterpret_cast<limb_t*>(&v)[q] = w[q];
+        for (int q = 0; q < NWD; q++) reinterpret_cast<limb_t*>(&v)[q] = w[q];
+      } else {
+        const limb_t* w = reinterpret_cast<const limb_t*>(p);
+#pragma unroll
+        for (int q = 0; q < NWD; q++) reinterpret_cast<limb_t*>(&v)[q] = w[q];
+      }
       return v;
     };
     Aff<F> e = ldaff(entry(top, 0));

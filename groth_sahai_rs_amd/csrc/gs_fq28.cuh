@@ -54,8 +54,8 @@ template <class C> struct Fq28 {
 #include "gs_mul28_asm.h"
 #if !defined(GS_NO_ASM_CALL) && !defined(GS_NO_POINT_ASM)
 // whole G1 point operations as subroutines with their own register allocation (gen_pointops_asm.py; used by gs_curve.cuh)
-#include "gs_pointops_asm.h"
 #define GS_POINT_ASM 1
+#include "gs_pointops_asm.h"
 #endif
 #endif
 

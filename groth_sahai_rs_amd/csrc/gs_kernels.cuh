@@ -14,6 +14,7 @@
 //   k_final    product of a cell's partial Miller values, final exponentiation,
 //              compare (verifier.rs:50-53)
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "gs_pairing.cuh"
@@ -109,7 +110,15 @@ __device__ __forceinline__ void seg_call(size_t g, const Pack<A...>& p, std::ind
 #ifndef GS_KSEG_ATTR
 #define GS_KSEG_ATTR
 #endif
-template <class Body, class... A> __global__ void __launch_bounds__(64, GS_WPE) GS_KSEG_ATTR k_seg(Segs<A...> S) {
+// waves per SIMD a body is BUILT for (the second argument of __launch_bounds__ = the minimum the compiler must allow:
+// 2 caps the kernel at 256 registers).  Default 1: every heavy kernel owns the whole register file of its SIMD.
+template <class B, class = void> struct BodyWpe {
+  static constexpr int v = GS_WPE;
+};
+template <class B> struct BodyWpe<B, std::void_t<decltype(B::WPE)>> {
+  static constexpr int v = B::WPE;
+};
+template <class Body, class... A> __global__ void __launch_bounds__(64, BodyWpe<Body>::v) GS_KSEG_ATTR k_seg(Segs<A...> S) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int s = 0;
   for (int i = 1; i < S.n; i++)
@@ -528,8 +537,14 @@ struct k_var {
 
 // joint MSM: one lane = one GrpTask (<= TMAX bases sharing a doubling chain; the lane's table build serves all of the
 // group's outputs, which run one after the other)
-template <class C, class F, int TMAX, int W>
+// WPE2 = 2 (G1 only): the kernel is built for TWO waves per SIMD.  With the point operations as register-only
+// subroutines (gs_pointops_asm.h: v48 .. v206 on BLS12-381) the whole lane fits 256 registers, and a second resident
+// wave issues into every slot the first one leaves empty -- at one wave per SIMD a v_mad_u64_u32 issues every ~5.9
+// cycles and a full-rate instruction every ~5.3, at two every ~4.75 / ~2.7 (tools/ubench.hip, profiles/r4/).  Planned
+// when the launch has enough waves to put two on every SIMD (csrc/gs_amd.hip, var_w2).
+template <class C, class F, int TMAX, int W, int WPE2 = 1>
 struct k_var_multi {
+  static constexpr int WPE = WPE2;
   static __device__ __forceinline__ void run(size_t w_in, size_t total, int ngrp, const GrpTask* grps, const VarTask* tasks,
                                                   ArrTab arrs, const Fr<C>* pool, int pool_n, Jac<F>* part,
                                                   int nslots, size_t g0, Aff<F>* tabws) {
@@ -557,7 +572,7 @@ struct k_var_multi {
     Fr<C> k[TMAX];
     for (uint32_t i = 0; i < gt.nt; i++) k[i] = pool[e * pool_n + tasks[gt.first[o] + i].s_idx];
     Jac<F> J;
-    jac_straus_run<C, F, TMAX, W>(J, k, (int)gt.nt, at, zback);
+    jac_straus_run<C, F, TMAX, W, true, (WPE2 == 2 ? 18 : 36)>(J, k, (int)gt.nt, at, zback);
     part[e * nslots + gt.slot[o]] = J;
   }
 }
@@ -603,7 +618,7 @@ struct k_var_tab {
       if (t.neg) negm |= 1u << i;
     }
     Jac<F> J;
-    jac_straus_run<C, F, TMAX, W>(J, k, (int)gt.nt, (const Aff<F>*)nullptr, one_of<F>(), tp, negm);
+    jac_straus_run<C, F, TMAX, W, true>(J, k, (int)gt.nt, (const Aff<F>*)nullptr, one_of<F>(), tp, negm);
     part[e * nslots + gt.slot[o]] = J;
   }
 }
@@ -619,24 +634,47 @@ struct k_fix {
   FixTask t = tasks[g % ntask];
   Jac<F> acc;
   jac_set_inf(acc);
-  for (int term = 0; term < 2; term++) {
-    int tb = term ? t.t1 : t.t0;
-    if (tb == 0xFF) continue;
-    Fr<C> k = pool[e * pool_n + (term ? t.s1 : t.s0)];
-    const Aff<F>* T = tab + (size_t)tb * 16 * 65536;  // 16-bit windows (k_build_tables16)
-    for (int w = 0; w < 16; w++) {
-      uint32_t d = (k.v[w >> 1] >> ((w & 1) * 16)) & 65535u;
-      if (d) {
-        Aff<F> q = T[(size_t)w * 65536 + d];
-        jac_madd(acc, acc, q);
-      }
-    }
+  // 2 x 16 window look-ups (16-bit windows, k_build_tables16) and the optional affine addend = up to 33 mixed
+  // additions.  The tables are 0.6 / 1.2 GB per CRS: every look-up is an HBM access, and at one wave per SIMD its whole
+  // latency is exposed unless it was requested a step ahead -- so the entry of step j + 1 is loaded (global_load:
+  // vmcnt only) before the addition of step j starts; the running sum is updated in place (G1: the register-only
+  // subroutines of gs_pointops_asm.h) and never has its address taken.
+  typedef const __attribute__((address_space(1))) limb_t* gptr;
+  auto ldaff = [](const Aff<F>* p) -> Aff<F> {
+    Aff<F> v;
+    constexpr int NWD = (int)(sizeof(Aff<F>) / sizeof(limb_t));
+    gptr w = (gptr) reinterpret_cast<const limb_t*>(p);
+#pragma unroll
+    for (int q = 0; q < NWD; q++) reinterpret_cast<limb_t*>(&v)[q] = w[q];
+    return v;
+  };
+  Fr<C> k0, k1;  // the (<= 2) scalars of this lane; an absent term keeps zero digits
+  for (int i = 0; i < FrM<C>::N; i++) k0.v[i] = k1.v[i] = 0;
+  if (t.t0 != 0xFF) k0 = pool[e * pool_n + t.s0];
+  if (t.t1 != 0xFF) k1 = pool[e * pool_n + t.s1];
+  auto slot = [&](int j) -> const Aff<F>* {  // j = term * 16 + window; nullptr = nothing to add
+    const int term = j >> 4, w = j & 15;
+    const Fr<C>& k = term ? k1 : k0;
+    const uint32_t d = (k.v[w >> 1] >> ((w & 1) * 16)) & 65535u;
+    const int tb = term ? t.t1 : t.t0;
+    if (d == 0 || tb == 0xFF) return nullptr;
+    return tab + ((size_t)tb * 16 + (size_t)w) * 65536 + d;
+  };
+  const Aff<F>* cur = slot(0);
+  Aff<F> q = ldaff(cur ? cur : tab);
+#pragma unroll 1
+  for (int j = 0; j < 32; j++) {
+    const Aff<F>* nxt = j + 1 < 32 ? slot(j + 1) : nullptr;
+    Aff<F> qn = ldaff(nxt ? nxt : tab);  // (a step without a look-up requests entry 0: harmless, never used)
+    if (cur) jac_madd_ip(acc, q);
+    q = qn;
+    cur = nxt;
   }
   if (t.a_arr != 0xFF) {
-    Aff<F> q;
-    aff_load<C>(q, arrs.base[t.a_arr] + e * arrs.stride[t.a_arr] + (size_t)t.a_idx * AFFB(C, F));
-    if (t.a_neg) q.y = neg(q.y);
-    jac_madd(acc, acc, q);
+    Aff<F> a;
+    aff_load<C>(a, arrs.base[t.a_arr] + e * arrs.stride[t.a_arr] + (size_t)t.a_idx * AFFB(C, F));
+    if (t.a_neg) a.y = neg(a.y);
+    jac_madd_ip(acc, a);
   }
   part[e * nslots + t.slot] = acc;
 }

@@ -120,6 +120,13 @@ int gs_sync(gs_ctx* ctx);                         /* hipStreamSynchronize on the
  * elsewhere) / unknown. */
 int gs_host_register(gs_ctx* ctx, void* ptr, size_t bytes);
 int gs_host_unregister(gs_ctx* ctx, void* ptr);
+/* The easy way to the same: gs_host_alloc returns `bytes` of host memory on a mapping of its own (page-aligned, never
+ * part of the allocator's heap), every page already touched (no first-touch faults inside a call: result arrays made
+ * per call cost 27-35 ms of them at 2^16), page-locked and registered -- a shim that keeps its Vec-like buffers in such
+ * memory gets DMA-direct transfers with one call per buffer.  gs_host_free drains every context, unregisters and unmaps.
+ * (What a Rust shim would wrap in a Drop type: INTEGRATION.md.) */
+int gs_host_alloc(gs_ctx* ctx, size_t bytes, void** out);
+int gs_host_free(gs_ctx* ctx, void* ptr);
 const char* gs_last_error(gs_ctx* ctx);
 const char* gs_version(void);
 /* sizes in bytes of the boundary PODs for a curve: out[0..5] = Fq, Fr, G1, G2, GT, CRS */

@@ -38,6 +38,13 @@ SHAPES = {
                                        line_tables=0, overlap=0),
     "pair3_straus2_lane_overlap": dict(red_k=1, miller_twin=2, miller_ch=3, var_tm=2, var_mo=1, var_w=4, coop_fe=0,
                                        line_tables=1, overlap=1),
+    # the G1 Straus lanes in the kernels BUILT FOR TWO WAVES PER SIMD (round 4: register-only G1 point operations leave
+    # room for it; planned for launches that put two waves on every SIMD, forced here on 66 equations), 4- and 8-term
+    # groups, 4- and 5-bit windows
+    "pair12_straus8x2w5_lane_w2": dict(red_k=4, miller_twin=2, miller_ch=12, var_tm=8, var_mo=2, var_w=5, coop_fe=0,
+                                      line_tables=1, overlap=0, var_w2=1),
+    "pair5dpp_straus4x4_coop_w2": dict(red_k=2, miller_twin=3, miller_ch=5, var_tm=4, var_mo=4, var_w=4, coop_fe=2,
+                                      line_tables=1, overlap=0, var_w2=1),
     # the verifier's Gamma^T c on window tables of the commitment components shared by all outputs (what large arities
     # use; forced here at 4 x 4): k_tab_build + k_var_tab8
     # (red_k=8: every output of a side behind one inversion)
@@ -106,11 +113,13 @@ def test_option_values_are_validated():
     eng = gs.Engine(0, 0)
     try:
         for key, bad in (("no_such_option", 1), ("miller_ch", 13), ("miller_twin", 4), ("var_tm", 9), ("var_mo", 3),
-                         ("var_w", 6), ("red_k", 3), ("var_ws_lanes", 100), ("coop_fe", 3), ("var_tab", 2), ("mixed_merge", 2)):
+                         ("var_w", 6), ("red_k", 3), ("var_ws_lanes", 100), ("coop_fe", 3), ("var_tab", 2), ("mixed_merge", 2),
+                         ("var_w2", 2)):
             with pytest.raises(gs.GsError):
                 eng.set_option(key, bad)
         for key, good in (("miller_ch", 12), ("var_mo", 4), ("var_w", 5), ("red_k", 4), ("var_ws_lanes", 128),
-                          ("miller_ch", 0), ("var_mo", 0), ("var_w", 0), ("red_k", 0), ("var_ws_lanes", 0)):
+                          ("miller_ch", 0), ("var_mo", 0), ("var_w", 0), ("red_k", 0), ("var_ws_lanes", 0), ("var_w2", 1),
+                          ("var_w2", -1), ("endo", 0), ("endo", 1)):
             eng.set_option(key, good)
     finally:
         eng.close()
