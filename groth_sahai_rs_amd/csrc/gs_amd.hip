@@ -1376,8 +1376,11 @@ static int run_side(gs_ctx* c, const char* tag, size_t N, SidePlan& sp, const Ar
       c->work_hint = (uint64_t)((double)N * sp.var.size() * ((double)n / (double)tot));  // terms
       // G1 lanes in the two-waves-per-SIMD build when the launch puts (nearly) two waves on every SIMD: fewer, and the
       // dispatcher doubles waves up on some SIMDs while others idle (measured in round 2: 27 ms instead of 17.7)
-      const bool w2 = std::is_same<F, Fq<C>>::value &&
-                      (c->var_w2 == 1 || (c->var_w2 < 0 && !c->rec && (double)n / 64.0 >= 1.75 * (double)c->simd_slots));
+      // MEASURED (round 4, gpurun_out/r4h): the verifier's 2048-wave launch at 2^16 takes 28.85 ms in the two-wave
+      // build against 29.07 ms in the one-wave build -- the multiply-add pipe is quarter rate whoever issues into
+      // it, and the 256-register build pays for the waits it hides with spills.  Kept as a forced shape (var_w2 = 1),
+      // never planned.
+      const bool w2 = std::is_same<F, Fq<C>>::value && c->var_w2 == 1;
 #define GS_VM(TM, WW)                                                                                                \
   do {                                                                                                               \
     if (w2)                                                                                                          \
@@ -2512,6 +2515,8 @@ int gs_ctx_create(int curve, int device, gs_ctx** out) {
   if (const char* e = getenv("GS_VAR_MO")) c->var_mo = atoi(e);
   if (const char* e = getenv("GS_VAR_W")) c->var_w = atoi(e);
   if (const char* e = getenv("GS_RED_K")) c->red_k = atoi(e);
+  if (const char* e = getenv("GS_VAR_W2")) c->var_w2 = atoi(e);
+  if (const char* e = getenv("GS_ENDO")) c->endo = atoi(e) != 0;
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return GS_ERR_DEVICE;
@@ -3442,6 +3447,17 @@ int gs_wire_decode_gt(gs_ctx* c, size_t n, int validate, const uint8_t* in, void
                        WireImpl<Bn254>::fields(c, 1, 1, validate, n, in, gt, ok));
 }
 
+#if defined(GS_DEBUG_STAMPS)
+// diagnosis build only: read and clear the phase stamps of the G1 / G2 Straus lanes (gs_curve.cuh, gs_dbg)
+int gs_debug_stamps(gs_ctx* c, unsigned long long* out16) {
+  RC(check_ctx(c, false));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(gs::gs_dbg), 16 * sizeof(unsigned long long)));
+  unsigned long long z[16] = {0};
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(gs::gs_dbg), z, sizeof z));
+  return GS_OK;
+}
+#endif
 int gs_prof_enable(gs_ctx* c, int on) {
   if (!c) return GS_ERR_ARG;
   c->prof = on != 0;

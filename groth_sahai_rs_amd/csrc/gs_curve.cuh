@@ -355,6 +355,100 @@ template <int NN, int ND> GS_HD void limb_divmod(uint32_t* q, uint32_t* rem, con
   }
   for (int i = 0; i < ND; i++) rem[i] = r[i];
 }
+// The same division by a COMPILE-TIME divisor D (the GLV / GLS decompositions divide by lambda = x^2 - 1 and by |x|): Barrett,
+// q^ = floor(n mu / 2^(32 NN)) with mu = floor(2^(32 NN) / D) evaluated by the compiler, then at most two corrections
+// (q - 2 <= q^ <= q).  ~150 instructions where the bit-by-bit loop above takes ~25 per bit x 256 bits -- round 4's phase
+// stamps put the digit preparation at 5 % of a G1 Straus lane (367 k of 7.3 M cycles per output, tools/straus_phases.py).
+template <int NN, int ND> struct BarrettMu {
+  uint32_t v[NN + 1];
+};
+template <int NN, int ND, class DT> constexpr BarrettMu<NN, ND> barrett_mu(const DT& d) {
+  BarrettMu<NN, ND> m{};
+  uint32_t r[ND + 1] = {};
+  for (int b = 32 * NN; b >= 0; b--) {
+    for (int i = ND; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 31);
+    r[0] = (r[0] << 1) | (b == 32 * NN ? 1u : 0u);
+    uint32_t t[ND + 1] = {};
+    uint32_t br = 0;
+    for (int i = 0; i <= ND; i++) {
+      uint64_t x = (uint64_t)r[i] - (i < ND ? (uint64_t)d[i] : 0u) - br;
+      t[i] = (uint32_t)x;
+      br = (uint32_t)(x >> 63);
+    }
+    if (!br) {
+      for (int i = 0; i <= ND; i++) r[i] = t[i];
+      m.v[b >> 5] |= 1u << (b & 31);
+    }
+  }
+  return m;
+}
+// D: a type with a static constexpr uint32_t array `d[ND]` (little-endian limbs, top limb non-zero)
+template <int NN, int ND, class D> GS_HD void limb_divmod_const(uint32_t* q, uint32_t* rem, const uint32_t* n) {
+  constexpr BarrettMu<NN, ND> MU = barrett_mu<NN, ND>(D::d);
+  constexpr int NM = NN - ND + 2;  // limbs of mu that can be non-zero (mu < 2^(32 (NN - ND) + 33))
+  static_assert(NM <= NN + 1, "divisor too short");
+  // t = n * mu, limbs NN .. NN + NM - 1 are q^ (the low limbs only matter through their carries)
+  uint32_t prod[NN + NM];
+  for (int i = 0; i < NN + NM; i++) prod[i] = 0;
+  for (int i = 0; i < NN; i++) {
+    uint64_t carry = 0;
+    for (int j = 0; j < NM; j++) {
+      uint64_t t = (uint64_t)n[i] * MU.v[j] + prod[i + j] + carry;
+      prod[i + j] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    prod[i + NM] = (uint32_t)carry;
+  }
+  uint32_t qh[NM];
+  for (int j = 0; j < NM; j++) qh[j] = prod[NN + j];
+  // r = n - q^ D on ND + 1 limbs (0 <= r < 3 D)
+  uint32_t qd[ND + 1];
+  for (int i = 0; i <= ND; i++) qd[i] = 0;
+  for (int i = 0; i < NM && i <= ND; i++) {
+    uint64_t carry = 0;
+    for (int j = 0; j < ND && i + j <= ND; j++) {
+      uint64_t t = (uint64_t)qh[i] * D::d[j] + qd[i + j] + carry;
+      qd[i + j] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    if (i + ND <= ND) qd[i + ND] += (uint32_t)carry;
+  }
+  uint32_t r[ND + 1];
+  {
+    uint32_t br = 0;
+    for (int i = 0; i <= ND; i++) {
+      uint64_t x = (uint64_t)(i < NN ? n[i] : 0u) - qd[i] - br;
+      r[i] = (uint32_t)x;
+      br = (uint32_t)(x >> 63);
+    }
+  }
+  for (int it = 0; it < 2; it++) {  // while (r >= D) { r -= D; q^++; }
+    uint32_t t[ND + 1];
+    uint32_t br = 0;
+    for (int i = 0; i <= ND; i++) {
+      uint64_t x = (uint64_t)r[i] - (i < ND ? D::d[i] : 0u) - br;
+      t[i] = (uint32_t)x;
+      br = (uint32_t)(x >> 63);
+    }
+    if (!br) {
+      for (int i = 0; i <= ND; i++) r[i] = t[i];
+      uint32_t c = 1;
+      for (int j = 0; j < NM; j++) {
+        uint64_t x = (uint64_t)qh[j] + c;
+        qh[j] = (uint32_t)x;
+        c = (uint32_t)(x >> 32);
+      }
+    }
+  }
+  for (int i = 0; i < NN; i++) q[i] = i < NM ? qh[i] : 0u;
+  for (int i = 0; i < ND; i++) rem[i] = r[i];
+}
+template <class C> struct DivLambda {
+  static constexpr const uint32_t (&d)[4] = C::LAMBDA;
+};
+template <class C> struct DivXabs {
+  static constexpr const uint32_t (&d)[2] = C::XABS_LIMBS;
+};
 // signed w=4 digits of an NL-limb value; nd = 8*NL + 1 digits
 template <int NL> GS_HD void recode_w4_limbs(int8_t* dg, const uint32_t* k) {
   uint32_t carry = 0;
@@ -511,7 +605,8 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fq<C>>& rout, const Aff
   uint32_t kk[8], q[8], k1[4], k2[4], lam[4];
   for (int i = 0; i < 8; i++) kk[i] = k.v[i];
   for (int i = 0; i < 4; i++) lam[i] = C::LAMBDA[i];
-  limb_divmod<8, 4>(q, k1, kk, lam);
+  limb_divmod_const<8, 4, DivLambda<C>>(q, k1, kk);
+  (void)lam;
   for (int i = 0; i < 4; i++) k2[i] = q[i];
   Jac<Fq<C>> tab[8];
   Aff<Fq<C>> at[8];
@@ -527,20 +622,20 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fq<C>>& rout, const Aff
   for (int i = 32; i >= 0; i--) {
     if (i != 32) {
 #pragma unroll 1
-      for (int d4 = 0; d4 < 4; d4++) jac_dbl(r, r);
+      for (int d4 = 0; d4 < 4; d4++) jac_dbl_ip(r);  // (G1 on the device: the register-only subroutines)
     }
     int a = d1[i];
     if (a != 0) {
       Aff<Fq<C>> t = at[(a < 0 ? -a : a) - 1];
       if (a < 0) t.y = neg(t.y);
-      jac_madd(r, r, t);
+      jac_madd_ip(r, t);
     }
     int b = d2[i];
     if (b != 0) {
       Aff<Fq<C>> t = at[(b < 0 ? -b : b) - 1];
       t.x = mul(t.x, beta);
       if (b < 0) t.y = neg(t.y);
-      jac_madd(r, r, t);
+      jac_madd_ip(r, t);
     }
   }
   r.z = mul(r.z, zback);
@@ -596,9 +691,10 @@ template <class C> GS_HD_NOINLINE void jac_smul_endo(Jac<Fp2<C>>& rout, const Af
   xa[0] = C::XABS_LIMBS[0];
   xa[1] = C::XABS_LIMBS[1];
   for (int j = 0; j < 3; j++) {
-    limb_divmod<8, 2>(q, d[j], n, xa);
+    limb_divmod_const<8, 2, DivXabs<C>>(q, d[j], n);
     for (int i = 0; i < 8; i++) n[i] = q[i];
   }
+  (void)xa;
   d[3][0] = n[0];
   d[3][1] = n[1];
   Jac<Fp2<C>> tab[8];
@@ -680,7 +776,8 @@ template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, c
   } else {
     uint32_t q[8], k1[4], k2[4], lam[4];
     for (int i = 0; i < 4; i++) lam[i] = C::LAMBDA[i];
-    limb_divmod<8, 4>(q, k1, kk, lam);
+    limb_divmod_const<8, 4, DivLambda<C>>(q, k1, kk);
+    (void)lam;
     for (int i = 0; i < 4; i++) k2[i] = q[i];
     recode_w_limbs<4, W>(dg, k1);
     recode_w_limbs<4, W>(dg + ND, k2);
@@ -701,9 +798,10 @@ template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, c
     xa[0] = C::XABS_LIMBS[0];
     xa[1] = C::XABS_LIMBS[1];
     for (int j = 0; j < 3; j++) {
-      limb_divmod<8, 2>(q, d[j], n, xa);
+      limb_divmod_const<8, 2, DivXabs<C>>(q, d[j], n);
       for (int i = 0; i < 8; i++) n[i] = q[i];
     }
+    (void)xa;
     d[3][0] = n[0];
     d[3][1] = n[1];
     for (int j = 0; j < 4; j++) {
@@ -729,6 +827,19 @@ template <class C, int W = 4> GS_HD void endo_digits(int8_t* dg, uint8_t* sgn, c
 // runtime's scratch pool only grants while no other queue holds any (it then limits the kernel's resident waves: the
 // same step took 1100-1700 ms instead of 320 ms after a small batch had run reductions on a side stream,
 // profiles/r3/scratch_pool.txt).  The kernels pass a second region of the lane's global workspace.
+#if defined(GS_DEBUG_STAMPS) && defined(__HIPCC__)
+// diagnosis build (tools/build_variant.sh stamps -DGS_DEBUG_STAMPS): lane 0 of every wave adds shader-cycle deltas of
+// the phases of the G1 Straus lanes to gs_dbg[]: 0 digits + top, 1 main loop, 2 inside the doubling subroutine calls,
+// 3 inside the addition steps (table wait + endomorphism + call), 4 waves, 5 the table build (k_var_multi)
+__device__ unsigned long long gs_dbg[16];
+#endif
+#if defined(GS_DEBUG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define GS_STAMP_T() __builtin_amdgcn_s_memtime()
+#define GS_STAMP_ADD(i, t) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gs_dbg[i], (unsigned long long)(t)); } while (0)
+#else
+#define GS_STAMP_T() 0ull
+#define GS_STAMP_ADD(i, t) do { } while (0)
+#endif
 #if defined(GS_STRAUS_INLINE)
 #define GS_STRAUS GS_HD
 #else
@@ -763,6 +874,7 @@ GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F
     //    ~6 k instructions: the HBM latency of the lane-contiguous tables disappears behind it) -- which only works
     //    because nothing else in the loop waits on vmcnt: the G1 point operations are register-only subroutines
     //    (jac_dbl_ip / jac_madd_ip) and the running sum never has its address taken.
+    unsigned long long st0 = GS_STAMP_T(), st_dbl = 0, st_add = 0;
     constexpr int NSL = E::NS * ND;                       // digits per term
     constexpr int ROWB = ((TMAX * NSL + 3) / 4 * 4);      // bytes per lane, whole dwords ...
     constexpr int ROW = ((ROWB / 4) % 2 == 0) ? ROWB + 4 : ROWB;  // ... an ODD number of them
@@ -813,10 +925,13 @@ GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F
       return v;
     };
     Aff<F> e = ldaff(entry(top, 0));
+    unsigned long long st1 = GS_STAMP_T();
     for (int i = top; i >= 0; i--) {
       if (i != top) {
+        unsigned long long sa = GS_STAMP_T();
 #pragma unroll 1
         for (int d4 = 0; d4 < W; d4++) jac_dbl_ip(r);
+        st_dbl += GS_STAMP_T() - sa;
       }
 #pragma unroll 1
       for (int k = 0; k < nk; k++) {
@@ -827,6 +942,7 @@ GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F
           if (ni >= 0) en = ldaff(entry(ni, k2));  // requested now, consumed after this step's addition
         }
         const int a = digit(i, k);
+        unsigned long long sb = GS_STAMP_T();
         if (a != 0) {
           const int t = k / E::NS, s2 = k % E::NS;
           Aff<F> u = e;
@@ -834,8 +950,17 @@ GS_STRAUS void jac_straus_run(Jac<F>& rout, const Fr<C>* ks, int nt, const Aff<F
           if (((a < 0) != (((sgm >> k) & 1) != 0)) != (((negm >> t) & 1) != 0)) u.y = neg(u.y);
           jac_madd_ip(r, u);
         }
+        st_add += GS_STAMP_T() - sb;
         e = en;
       }
+    }
+    {
+      unsigned long long st2 = GS_STAMP_T();
+      GS_STAMP_ADD(0, st1 - st0);
+      GS_STAMP_ADD(1, st2 - st1);
+      GS_STAMP_ADD(2, st_dbl);
+      GS_STAMP_ADD(3, st_add);
+      GS_STAMP_ADD(4, 1);
     }
 #else
     int8_t dg[TMAX][E::NS * ND];

@@ -613,8 +613,114 @@ template <class C> GS_HD bool is_zero(const Fq28<C>& a) {
 }
 template <class C> GS_HD bool eq(const Fq28<C>& a, const Fq28<C>& b) { return is_zero(sub(a, b)); }
 
+// ---- inversion --------------------------------------------------------------------------------------------------
+// Round 4: constant-time "safegcd" (Bernstein-Yang divsteps, the half-delta variant as in libsecp256k1's modinv32) on
+// signed 28-bit limbs, instead of Fermat's a^(p-2) (380 squarings + ~100 products = ~190 k instructions per lane).
+// INV_DIVSTEPS divsteps suffice for a p of this size; they run in groups of 28 on the low words of (f, g) -- 17
+// branch-free operations each -- and every group is applied to the full-length (f, g) and (d, e) as one 2 x 2 matrix:
+// ~23 k instructions per inversion, uniform control flow (every lane runs the same fixed number of groups).
+// Every reduction kernel (one inversion per lane of up to 8 outputs), the final exponentiation's easy part and the
+// square-root / decode paths sit behind this; at small batches an inversion is a serial 0.3-0.4 ms each.
+//   value in:  V = a R (any lazily reduced representative);  x = V mod p in [0, p)
+//   safegcd:   y = x^-1 mod p = a^-1 R^-1;   out = y R^3 R^-1 = a^-1 R   (one product by RRR28 = R^3 mod p)
+// inv(0) = 0 (f stays p, d stays 0).  -DGS_INV_FERMAT keeps the exponentiation.
+template <class C> GS_HD void inv28_divsteps(int32_t& zeta, uint32_t f0, uint32_t g0, int32_t (&t)[4]) {
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+#pragma unroll
+  for (int i = 0; i < 28; i++) {
+    uint32_t m1 = (uint32_t)(zeta >> 31);  // zeta < 0
+    uint32_t m2 = 0u - (g & 1u);           // g odd
+    uint32_t x = (f ^ m1) - m1, y = (u ^ m1) - m1, z = (v ^ m1) - m1;  // conditionally negated f, u, v
+    g += x & m2;
+    q += y & m2;
+    r += z & m2;
+    m1 &= m2;
+    zeta = (int32_t)((uint32_t)zeta ^ m1) - 1;  // -zeta - 2 or zeta - 1
+    f += g & m1;
+    u += q & m1;
+    v += r & m1;
+    g >>= 1;
+    u <<= 1;
+    v <<= 1;
+  }
+  t[0] = (int32_t)u, t[1] = (int32_t)v, t[2] = (int32_t)q, t[3] = (int32_t)r;
+}
+template <class C> GS_HD_NOINLINE void inv28_safegcd(limb_t* out, const limb_t* in) {
+  constexpr int L = C::L;
+  constexpr int GROUPS = (C::INV_DIVSTEPS + 1 + 27) / 28;
+  constexpr uint32_t PINV = (0u - C::P28_INV) & (uint32_t)M28;  // p^-1 mod 2^28
+  // x = the canonical representative of the input value
+  Fq28<C> a;
+  for (int i = 0; i < L; i++) a.v[i] = in[i];
+  Fq28<C> tt = norm_full(mul(a, fq_one<C>()));  // value in (-p/2, 3p/2), unique limbs
+  Fq28<C> pp;
+  for (int i = 0; i < L; i++) pp.v[i] = C::P28[i];
+  Fq28<C> plus = norm_full(add(tt, pp)), minus = norm_full(sub(tt, pp));
+  Fq28<C> cx = tt.v[L - 1] < 0 ? plus : (minus.v[L - 1] >= 0 ? minus : tt);
+  int32_t f[L], g[L], d[L], e[L];
+  for (int i = 0; i < L; i++) {
+    f[i] = C::P28[i];
+    g[i] = (int32_t)cx.v[i];
+    d[i] = 0;
+    e[i] = i == 0 ? 1 : 0;
+  }
+  int32_t zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < GROUPS; it++) {
+    int32_t t[4];
+    inv28_divsteps<C>(zeta, (uint32_t)f[0] | ((uint32_t)f[1] << 28), (uint32_t)g[0] | ((uint32_t)g[1] << 28), t);
+    const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+    {  // (d, e) <- t (d, e) / 2^28 mod p, kept in (-2p, p)
+      const int32_t sd = d[L - 1] >> 31, se = e[L - 1] >> 31;
+      int32_t md = (t[0] & sd) + (t[1] & se), me = (t[2] & sd) + (t[3] & se);
+      int64_t cd = u * d[0] + v * e[0], ce = q * d[0] + r * e[0];
+      md -= (int32_t)((PINV * (uint32_t)cd + (uint32_t)md) & (uint32_t)M28);
+      me -= (int32_t)((PINV * (uint32_t)ce + (uint32_t)me) & (uint32_t)M28);
+      cd += (int64_t)C::P28[0] * md;
+      ce += (int64_t)C::P28[0] * me;
+      cd >>= 28;
+      ce >>= 28;
+#pragma unroll
+      for (int i = 1; i < L; i++) {
+        cd += u * d[i] + v * e[i] + (int64_t)C::P28[i] * md;
+        ce += q * d[i] + r * e[i] + (int64_t)C::P28[i] * me;
+        d[i - 1] = (int32_t)cd & M28;
+        e[i - 1] = (int32_t)ce & M28;
+        cd >>= 28;
+        ce >>= 28;
+      }
+      d[L - 1] = (int32_t)cd;
+      e[L - 1] = (int32_t)ce;
+    }
+    {  // (f, g) <- t (f, g) / 2^28 (exact)
+      int64_t cf = u * f[0] + v * g[0], cg = q * f[0] + r * g[0];
+      cf >>= 28;
+      cg >>= 28;
+#pragma unroll
+      for (int i = 1; i < L; i++) {
+        cf += u * f[i] + v * g[i];
+        cg += q * f[i] + r * g[i];
+        f[i - 1] = (int32_t)cf & M28;
+        g[i - 1] = (int32_t)cg & M28;
+        cf >>= 28;
+        cg >>= 28;
+      }
+      f[L - 1] = (int32_t)cf;
+      g[L - 1] = (int32_t)cg;
+    }
+  }
+  // g = 0, f = +-1 (or +-p for x = 0): y = sign(f) d, brought from (-2p, p) into a lazily reduced internal value
+  Fq28<C> y;
+  const bool fneg = f[L - 1] < 0;
+  for (int i = 0; i < L; i++) y.v[i] = fneg ? -d[i] : d[i];
+  Fq28<C> k;
+  for (int i = 0; i < L; i++) k.v[i] = C::RRR28[i];
+  Fq28<C> res = mul(norm(y), k);  // |y| < 2p: far inside the mul contract
+  for (int i = 0; i < L; i++) out[i] = res.v[i];
+}
+
 // a^(p-2); inv(0) = 0.  4-bit fixed window over the constant exponent.
-template <class C> GS_HD_NOINLINE void inv28_raw(limb_t* out, const limb_t* in) {
+template <class C> GS_HD_NOINLINE void inv28_fermat(limb_t* out, const limb_t* in) {
   Fq28<C> a;
   for (int i = 0; i < C::L; i++) a.v[i] = in[i];
   Fq28<C> tab[16];
@@ -641,6 +747,13 @@ template <class C> GS_HD_NOINLINE void inv28_raw(limb_t* out, const limb_t* in) 
     }
   }
   for (int i = 0; i < C::L; i++) out[i] = r.v[i];
+}
+template <class C> GS_HD void inv28_raw(limb_t* out, const limb_t* in) {
+#if defined(GS_INV_FERMAT)
+  inv28_fermat<C>(out, in);
+#else
+  inv28_safegcd<C>(out, in);
+#endif
 }
 template <class C> GS_HD Fq28<C> inv(const Fq28<C>& a) {
   Fq28<C> n = norm(a), r;

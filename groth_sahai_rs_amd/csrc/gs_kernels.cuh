@@ -566,7 +566,9 @@ struct k_var_multi {
       aff_load<C>(P[i], arrs.base[t.p_arr] + e * arrs.stride[t.p_arr] + (size_t)t.p_idx * AFFB(C, F));
       if (t.neg) P[i].y = neg(P[i].y);
     }
+    unsigned long long sb0 = GS_STAMP_T();
     jac_straus_build<C, F, TMAX, W>(at, zback, P, (int)gt.nt, jt);
+    GS_STAMP_ADD(5, GS_STAMP_T() - sb0);
   }
   for (uint32_t o = 0; o < gt.no; o++) {
     Fr<C> k[TMAX];

@@ -463,7 +463,7 @@ GS_HD void multi_miller_pair(Fp12<C>& fout, int a, const Aff<Fq<C>>* ps, const A
 
 // f^|x| by square-and-multiply over the 64-bit curve parameter, cyclotomic
 // squarings; then conjugate if x < 0 (so the result is f^x).
-template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f) {
+template <class C> GS_HD_NOINLINE void f12_exp_by_x_gs(Fp12<C>& r, const Fp12<C>& f) {
   Fp12<C> acc = f;
   int top = 63;
   while (!((C::X_ABS >> top) & 1)) top--;
@@ -490,6 +490,120 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f
   }
   if (C::X_NEG) f12_conj(acc, acc);
   r = acc;
+}
+
+// ---- Karabina's compressed squarings (round 4) ------------------------------------------------------
+// In the cyclotomic subgroup the Granger-Scott squaring is three Fp4 squarings on the coefficient pairs
+//   (z0, z1) = (c0.c0, c1.c1),  (z2, z3) = (c1.c0, c0.c2),  (z4, z5) = (c0.c1, c1.c2)      [f12_cyclo_sqr_inl]
+// and the new (z2, z3, z4, z5) depend on the old (z2, z3, z4, z5) ALONE: a run of squarings can drop (z0, z1) -- two Fp4
+// squarings per step instead of three, and a working set of 4 Fp2 that never leaves the registers -- and recover them
+// where a value is needed (Karabina, "Squaring in cyclotomic subgroups", Math. Comp. 2013; g_i = z_i):
+//     z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2),      z0 = xi (2 z1^2 + z2 z5 - 3 z3 z4) + 1.
+// f^|x| = product over the set bits b of x of f^(2^b): ONE chain of top(x) compressed squarings, the (<= 6) values at the
+// set bits saved, all of them decompressed behind ONE inversion (Montgomery's trick over their 4 z2; the inversion itself
+// is the safegcd of gs_fq28.cuh) and multiplied.  Checked against the big-integer oracle on both towers
+// (tools: the closure and the two formulas hold with xi the Fp6 non-residue and w^2 = v).  BLS12-381: x has 6 set
+// bits; 63 steps of 4 Fp2 products instead of 6, +6 decompressions (3 squarings + 3 products each) + one shared
+// inversion: ~0.85 of the Granger-Scott run's multiply-adds and none of its accumulator traffic.  A z2 that is 0 (f = 1
+// -- an all-identity pairing product -- is the case that occurs) sends the lane to the uncompressed routine.  BN254's
+// x has 26 set bits: the decompressions would cost more than the squarings save, it keeps the uncompressed run.
+template <class C> GS_HD void cyclo_sqr_compressed(Fp2<C>& g2, Fp2<C>& g3, Fp2<C>& g4, Fp2<C>& g5) {
+  Fp2<C> t2, t3, t4, t5;
+  fp4_sqr(t2, t3, g2, g3);
+  fp4_sqr(t4, t5, g4, g5);
+  // z2 = 3 xi t5 + 2 z2 ; z3 = 3 t4 - 2 z3 ; z4 = 3 t2 - 2 z4 ; z5 = 3 t3 + 2 z5
+  Fp2<C> x5 = norm(mul_xi(t5));
+  Fp2<C> z = add(x5, g2);
+  g2 = norm(add(dbl(z), x5));
+  z = sub(t4, g3);
+  g3 = norm(add(dbl(z), t4));
+  z = sub(t2, g4);
+  g4 = norm(add(dbl(z), t2));
+  z = add(t3, g5);
+  g5 = norm(add(dbl(z), t3));
+}
+template <class C> constexpr int x_popcount() {
+  int n = 0;
+  for (int i = 0; i < 64; i++) n += (int)((C::X_ABS >> i) & 1);
+  return n;
+}
+template <class C> GS_HD_NOINLINE void f12_exp_by_x_karabina(Fp12<C>& r, const Fp12<C>& f) {
+  constexpr int NS = x_popcount<C>() - (int)(C::X_ABS & 1);  // values saved along the chain (bit 0 is f itself)
+  Fp2<C> sv[NS][4];
+  Fp2<C> g2 = f.c1.c0, g3 = f.c0.c2, g4 = f.c0.c1, g5 = f.c1.c2;
+  int top = 63;
+  while (!((C::X_ABS >> top) & 1)) top--;
+  int ns = 0, since = 0;
+#pragma unroll 1
+  for (int i = 1; i <= top; i++) {
+    cyclo_sqr_compressed<C>(g2, g3, g4, g5);
+    if (++since == 3) {  // the squaring feeds 2 z back linearly: bring the VALUES back to ~[-p, p] now and then
+#define GS_VR2(x) x.c0 = vreduce(x.c0), x.c1 = vreduce(x.c1)
+      GS_VR2(g2);
+      GS_VR2(g3);
+      GS_VR2(g4);
+      GS_VR2(g5);
+#undef GS_VR2
+      since = 0;
+    }
+    if ((C::X_ABS >> i) & 1) {
+      sv[ns][0] = g2, sv[ns][1] = g3, sv[ns][2] = g4, sv[ns][3] = g5;
+      ns++;
+    }
+  }
+  // 1 / (4 z2) for all saved values behind one inversion
+  Fp2<C> den[NS], pre[NS];
+  Fp2<C> acc = one_of<Fp2<C>>();
+  bool degenerate = false;
+  for (int k = 0; k < NS; k++) {
+    den[k] = norm(dbl(dbl(sv[k][0])));
+    degenerate |= is_zero(den[k]);
+    pre[k] = acc;
+    acc = mul(acc, den[k]);
+  }
+  if (degenerate) {  // z2 = 0 somewhere (f = 1): the uncompressed run handles every element of the subgroup
+    f12_exp_by_x_gs(r, f);
+    return;
+  }
+  Fp2<C> suf = inv(acc);
+  Fp12<C> out;
+  bool have = false;
+  if (C::X_ABS & 1) {
+    out = f;
+    have = true;
+  }
+  for (int k = NS - 1; k >= 0; k--) {
+    Fp2<C> i4z2 = mul(suf, pre[k]);
+    suf = mul(suf, den[k]);
+    const Fp2<C>&z2 = sv[k][0], &z3 = sv[k][1], &z4 = sv[k][2], &z5 = sv[k][3];
+    // z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2)        (lazy sum: 2 + 3 + 2 limb-growth units, one carry round)
+    Fp2<C> s4 = sqr(z4);
+    Fp2<C> num = norm(sub(add(mul_xi(sqr(z5)), add(dbl(s4), s4)), dbl(z3)));
+    Fp2<C> z1 = mul(num, i4z2);
+    // z0 = xi (2 z1^2 + z2 z5 - 3 z3 z4) + 1
+    Fp2<C> b = mul(z3, z4);
+    Fp2<C> t = norm(sub(add(dbl(sqr(z1)), mul(z2, z5)), add(dbl(b), b)));
+    Fp2<C> z0 = norm(add(mul_xi(t), one_of<Fp2<C>>()));
+    Fp12<C> v;
+    v.c0.c0 = z0, v.c1.c1 = z1, v.c1.c0 = z2, v.c0.c2 = z3, v.c0.c1 = z4, v.c1.c2 = z5;
+    if (have) {
+      f12_mul(out, out, v);
+    } else {
+      out = v;
+      have = true;
+    }
+  }
+  if (C::X_NEG) f12_conj(out, out);
+  r = out;
+}
+template <class C> GS_HD void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f) {
+#if !defined(GS_NO_KARABINA)
+  if constexpr (x_popcount<C>() <= 8) {
+    f12_exp_by_x_karabina(r, f);
+    return;
+  }
+#endif
+  f12_exp_by_x_gs(r, f);
 }
 
 // Final exponentiation, arkworks' exponent.  `ex(r, f)` computes r = f^x: one lane

@@ -88,6 +88,8 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "overlap"       1 independent kernels of a small batch on internal side streams | 0 one stream
  *   "var_tab"      -1 planned | 0 the verifier's Gamma^T c on Straus lanes with their own tables | 1 on window tables of
  *                   the commitment components shared by all outputs (8-bit windows; what large arities use)
+ *   "var_w2"       -1 planned | 0 | 1 the G1 Straus lanes in the kernels built for TWO waves per SIMD (256 registers: the
+ *                   register-only G1 point operations leave room); planned when a launch puts two waves on every SIMD
  *   "endo"          1 (default) GLV / psi-GLS scalar multiplications: r-torsion points only | 0 every variable-base scalar
  *                   multiplication is a plain signed-window double-and-add lane ("k_var.plain", "k_smul_batch.plain"):
  *                   defined on ANY curve point, like the reference's Com::scalar_mul (data_structures.rs:336-342), at
@@ -97,7 +99,8 @@ int gs_set_stream(gs_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default
  *   "mixed_merge"  -1 planned (merged up to 2^14 equations per call on a 256-CU device) | 0 the parts of a mixed call run
  *                   one after the other | 1 their launches are merged
  * The same knobs are read ONCE at gs_ctx_create from the environment for experiments without recompiling the caller:
- * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_VAR_MO, GS_VAR_W, GS_RED_K, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP (same values).
+ * GS_MILLER_TWIN, GS_MILLER_CH, GS_VAR_TM, GS_VAR_MO, GS_VAR_W, GS_VAR_W2, GS_RED_K, GS_COOP_FE, GS_LINE_TABLES, GS_OVERLAP,
+ * GS_ENDO (same values).
  * Unset = planned.  GS_COPY_THREADS (default 4): memcpy workers of the host-pointer entry points; GS_ROCTX=1: load the
  * roctx library for phase markers ("gs.prove", "gs.prove.g1", "gs.verify.miller" ...) even when no profiler mapped it.
  * Diagnostics on stderr: GS_PLAN_TRACE=1 (the verifier's Miller plan per call: mode, budget, tasks per equation, planned

@@ -71,6 +71,27 @@ def test_field_ops(twin, cname):
 
 
 @pytest.mark.parametrize("cname", CURVES)
+def test_inversion_safegcd(twin, cname):
+    """Round 4: inv() is the constant-time safegcd (divsteps in groups of 28 on signed 28-bit limbs, gs_fq28.cuh), not
+    Fermat any more: 400 random values, powers of two and their neighbours, values next to 0 and p, and inv(0) = 0
+    (what the reduction kernels rely on for identity slots) against Python's modular inverse."""
+    c = curve(cname)
+    rng = np.random.default_rng(2024)
+    vals = [int.from_bytes(rng.bytes(64), "little") % c.p for _ in range(400)]
+    vals += [1, 2, 3, c.p - 1, c.p - 2, (c.p - 1) // 2, (c.p + 1) // 2]
+    for k in range(1, c.p.bit_length(), 7):
+        vals += [(1 << k) % c.p, ((1 << k) - 1) % c.p, (c.p - (1 << k)) % c.p]
+    inv = getattr(twin, "twin_fp_inv_" + cname)
+    for a in vals:
+        out = np.zeros(c.nq, dtype=np.uint64)
+        inv(ptr(c.fq(a)), ptr(out))
+        assert c.fq_dec(out) == pow(a, -1, c.p), hex(a)
+    out = np.ones(c.nq, dtype=np.uint64)
+    inv(ptr(c.fq(0)), ptr(out))
+    assert c.fq_dec(out) == 0
+
+
+@pytest.mark.parametrize("cname", CURVES)
 def test_smul_golden(twin, cname):
     c = curve(cname)
     g = c.golden
