@@ -360,6 +360,10 @@ class Prog2:
         self.inputs[name + ".0"], self.inputs[name + ".1"] = 2 * k, 2 * k + 1
         return (name + ".0", name + ".1")
 
+    def inp_q(self, name, k, qk):
+        """an operand of the addend (read once): the compact form takes it in AGPRs"""
+        return self.inp(name, k)
+
     def outp(self, val, k):
         self.outputs[val[0]], self.outputs[val[1]] = 2 * k, 2 * k + 1
 
@@ -699,8 +703,400 @@ class Prog2:
         self.out.append("v_and_b32 %s, %s, %s" % (self.vr(D, 0), M28, self.vr(D, 0)))
 
 
-def g2_dbl(L):
-    p = Prog2(L, 6)
+# ======================================================================================================================
+# G2, compact form (round 4, after the straight-line form lost to the instruction cache): the SAME symbolic programs, but
+# every Fp2 product / squaring is a call of the SHARED subroutine of gs_mul28_asm.h (gs_fp2mul28_sub_L: a in v0.., b in
+# v2L.., result in v4L.., -a1 in v6L..; gs_fp2sqr28_sub_L: a in v0.., result in v2L.., three temporaries above it), and what
+# this generator owns is the data movement around them: operands copied into the subroutine's blocks (from a VGPR block or
+# straight from an AGPR), results consumed where the subroutine leaves them, values that must outlive a call moved to the
+# I/O blocks or parked in AGPRs by the same farthest-next-use rule.  ~1.6 k instructions of glue per addition next to the
+# 13.2 k of its seven products and four squarings -- and the code is 13 KB instead of 114 KB.
+#     return address   s[36:37] (the nested calls use s[34:35]);  subroutine addresses in s[56:57] (product), s[58:59]
+# ======================================================================================================================
+class Prog2c(Prog2):
+    NPARK = 8          # parking blocks a0 .. a(8L-1); the addend's four blocks follow them
+
+    def __init__(self, L, nio, nio_v=6):
+        # nio is ignored (signature of Prog2: the program builders pass their block count); nio_v = in/out VGPR blocks.
+        # the addend is read ONCE per coordinate: it arrives in AGPRs (4 blocks after the parking space) and goes straight
+        # into the multiplier's operand block.  The VGPR footprint ends at v(7L+4+6L+5): the caller keeps 65 (L = 14)
+        # VGPRs of its own across the call -- enough for the table entry it has requested for the NEXT step, whose loads
+        # are still in flight (with the addend in VGPR I/O blocks the call clobbered all but 9 and every step waited
+        # for its prefetch: k_fix.g2 12.3 -> 14.7 ms)
+        Prog2.__init__(self, L, nio_v)
+        top = self.io_base + nio_v * L
+        self.t = "v%d" % top
+        self.hout = ["v%d" % (top + 1 + i) for i in range(4)]
+        self.top = top + 5
+        self.ablocks = [k * L for k in range(self.NPARK)]
+        self.ain_base = self.NPARK * L
+        self.ainputs = {}
+
+    def inp_q(self, name, k, qk):
+        self.ainputs[name + ".0"], self.ainputs[name + ".1"] = 2 * qk, 2 * qk + 1
+        return (name + ".0", name + ".1")
+
+    SEARCH = 1500      # schedules tried per subroutine (fixed seed: the generated header is reproducible)
+
+    def compile(self):
+        """The order of the symbolic program decides how many values a call finds in the blocks it destroys: try random
+        topological orders of the dependency graph (reads after their writer, an in-place carry round `norm` after every
+        earlier reader of its value) and keep the one with the least data movement."""
+        import random
+        ops = list(self.ops)
+        n = len(ops)
+
+        def rw(op):
+            k = op[0]
+            if k in ("fp2mul", "fp2sqr"):
+                return self._srcs(op), list(op[1])
+            if k == "lin":
+                return self._srcs(op), [op[2]]
+            if k == "norm":
+                return [op[1]], [op[1]]
+            return self._srcs(op), []          # export
+
+        pred = [set() for _ in range(n)]
+        last_w, readers = {}, {}
+        for i, op in enumerate(ops):
+            r, w = rw(op)
+            for x in r:
+                if x in last_w:
+                    pred[i].add(last_w[x])
+            for x in w:
+                if x in last_w:
+                    pred[i].add(last_w[x])
+                for j in readers.get(x, ()):
+                    if j != i:
+                        pred[i].add(j)
+                last_w[x] = i
+                readers[x] = []
+            for x in r:
+                readers.setdefault(x, []).append(i)
+        rnd = random.Random(20241005 + self.L + n)
+        best = None
+        for trial in range(self.SEARCH + 1):
+            if trial == 0:
+                order = list(range(n))
+            else:
+                done, order = set(), []
+                ready = [i for i in range(n) if not pred[i]]
+                while ready:
+                    # mostly follow the original order, sometimes jump: nearby schedules, not noise
+                    ready.sort()
+                    i = ready[0] if rnd.random() < 0.6 else rnd.choice(ready)
+                    ready.remove(i)
+                    order.append(i)
+                    done.add(i)
+                    for j in range(n):
+                        if j not in done and j not in ready and pred[j] <= done:
+                            ready.append(j)
+                assert len(order) == n
+            self.ops = [ops[i] for i in order]
+            self.out, self.stats = [], {"park": 0, "unpark": 0, "mov": 0}
+            try:
+                self._compile_order()
+            except AssertionError:
+                continue
+            if best is None or len(self.out) < len(best[0]):
+                best = (self.out, self.stats, self.peak_park, list(self.ops))
+        assert best is not None
+        self.out, self.stats, self.peak_park, self.ops = best
+
+    def _compile_order(self):
+        L, ops = self.L, self.ops
+        W = [k * L for k in range(7)]
+        allv = list(W) + [self.io_base + k * L for k in range(self.nio)]
+        uses = {}
+        for idx, op in enumerate(ops):
+            for v in self._srcs(op):
+                uses.setdefault(v, []).append(idx)
+        final = len(ops)
+        for v in self.outputs:
+            uses.setdefault(v, []).append(final)
+        where_v, where_a = {}, {}
+        afree = list(self.ablocks)
+        for v, k in self.inputs.items():
+            where_v[v] = self.io_base + k * L
+        for v, k in self.ainputs.items():
+            where_a[v] = self.ain_base + k * L    # (parking space once the coordinate has been consumed)
+        self.peak_park = 0
+        self.stats["calls"] = 0
+        o = self.out
+        o.append("s_mov_b64 s[36:37], s[34:35]")
+        # Until the "export" op (the H = 0 test of the addition) NOTHING the caller handed in may be overwritten: the
+        # subroutine returns early from there with every operand intact (see the op).  -1: no such op (doubling).
+        exp_idx = max([i for i, op in enumerate(ops) if op[0] == "export"] + [-1])
+        io_blocks = {self.io_base + k * L for k in range(self.nio)}
+        deferred_a = []
+
+        def next_use(v, idx):
+            for u in uses.get(v, []):
+                if u >= idx:
+                    return u
+            return None
+
+        def free_blocks():
+            occ = set(where_v.values())
+            return [b for b in allv if b not in occ]
+
+        def drop_dead(idx):
+            for v in list(where_v):
+                if next_use(v, idx) is None:
+                    where_v.pop(v)
+            for v in list(where_a):
+                if next_use(v, idx) is None:
+                    ab = where_a.pop(v)            # (the addend's blocks too: they are in/out operands, "destroyed")
+                    if ab >= self.ain_base and idx <= exp_idx:
+                        deferred_a.append(ab)      # ... but only after the early-exit point
+                    else:
+                        afree.append(ab)
+            if idx > exp_idx and deferred_a:
+                afree.extend(deferred_a)
+                del deferred_a[:]
+
+        def park(v):
+            """VGPR copy of v goes away; make sure an AGPR copy exists"""
+            b = where_v.pop(v)
+            if v not in where_a:
+                assert afree, "out of parking blocks"
+                ab = afree.pop(0)
+                where_a[v] = ab
+                for i in range(L):
+                    o.append("v_accvgpr_write_b32 a%d, %s" % (ab + i, self.vr(b, i)))
+                self.stats["park"] += 1
+                self.peak_park = max(self.peak_park, len(where_a))
+            return b
+
+        def get_v(idx, locked, avoid=(), prefer=None):
+            if idx <= exp_idx:
+                avoid = set(avoid) | io_blocks
+            fr = [b for b in free_blocks() if b not in avoid]
+            if prefer is not None and prefer in fr:
+                return prefer
+            fr.sort(key=lambda b: (b < self.io_base, b))      # I/O blocks first: the work blocks turn over at every call
+            if fr:
+                return fr[0]
+            best, far = None, -1
+            for v, b in where_v.items():
+                if v in locked or b in avoid:
+                    continue
+                nu = next_use(v, idx)
+                nu = 10 ** 9 if nu is None else nu
+                if nu > far:
+                    best, far = v, nu
+            assert best is not None, "no VGPR block to evict at op %d" % idx
+            if next_use(best, idx) is None:
+                return where_v.pop(best)
+            return park(best)
+
+        def ensure_v(v, idx, locked, avoid=()):
+            if v in where_v:
+                return where_v[v]
+            assert v in where_a, "value %s is nowhere at op %d" % (v, idx)
+            b = get_v(idx, locked, avoid)
+            ab = where_a[v]
+            for i in range(L):
+                o.append("v_accvgpr_read_b32 %s, a%d" % (self.vr(b, i), ab + i))
+            where_v[v] = b
+            self.stats["unpark"] += 1
+            return b
+
+        def mov(dst, src):
+            for i in range(L):
+                o.append("v_mov_b32 %s, %s" % (self.vr(dst, i), self.vr(src, i)))
+            self.stats["mov"] += 1
+
+        def call(idx, operands, nclob, results, addr):
+            """operands: values wanted in W[0..]; the call destroys W[len(operands) .. len(operands)+nclob-1] (results first)"""
+            n = len(operands)
+            tgt = {W[k]: operands[k] for k in range(n)}
+            blocks = set(W[:n + nclob])
+            locked = set(operands)
+            # 1. values the call would destroy and that are needed later (or are no operand of it) leave its blocks
+            for v, b in list(where_v.items()):
+                if b not in blocks:
+                    continue
+                if v in operands:
+                    continue                      # the parallel move below takes care of it
+                if next_use(v, idx + 1) is None and next_use(v, idx) is None:
+                    where_v.pop(v)
+                    continue
+                fr = [x for x in free_blocks() if x not in blocks]
+                if fr and v not in where_a:
+                    fr.sort()
+                    mov(fr[0], b)
+                    where_v[v] = fr[0]
+                else:
+                    park(v)
+            # an operand that must survive the call but sits in a block the call destroys, and is not moved into a
+            # preserved block by the call's own placement: same treatment (it then comes back from where it went)
+            # 2. parallel move of the operands into W[0..n-1]
+            pending = {}
+            for t, v in tgt.items():
+                if where_v.get(v) == t:
+                    continue
+                pending[t] = v
+            # operands living in a destroyed block that are needed after the call and are NOT about to be moved to an
+            # operand block: cannot happen (every operand is moved into or already sits in an operand block)
+            guard = 0
+            while pending:
+                guard += 1
+                assert guard < 64
+                srcblocks = {where_v[v] for v in pending.values() if v in where_v}
+                done = False
+                for t, v in list(pending.items()):
+                    if t in srcblocks and where_v.get(v) != t:
+                        # t still holds a value somebody else wants moved out first
+                        holder = [u for u in pending.values() if where_v.get(u) == t]
+                        if holder:
+                            continue
+                    if v in where_v:
+                        s_ = where_v[v]
+                        mov(t, s_)
+                        if s_ in blocks or next_use(v, idx + 1) is None:
+                            where_v[v] = t          # moved (or dead after the call anyway)
+                        # else: copied; the original stays the value's home, the copy is transient
+                        elif True:
+                            pass
+                    else:
+                        ab = where_a[v]
+                        for i in range(L):
+                            o.append("v_accvgpr_read_b32 %s, a%d" % (self.vr(t, i), ab + i))
+                        self.stats["unpark"] += 1
+                        if next_use(v, idx + 1) is None:
+                            pass
+                    pending.pop(t)
+                    done = True
+                    break
+                if not done:
+                    # a cycle among the operand blocks: one of them steps aside into the last block the call destroys
+                    t, v = next(iter(pending.items()))
+                    u = [x for x in pending.values() if where_v.get(x) == t][0]
+                    tmp = W[n + nclob - 1]
+                    assert tmp not in where_v.values()
+                    mov(tmp, t)
+                    where_v[u] = tmp
+            # transient copies must not be mistaken for homes: a value whose home is outside `blocks` keeps it
+            o.append("s_swappc_b64 s[34:35], %s" % addr)
+            self.stats["calls"] += 1
+            # whatever still claims a destroyed block is gone now (operands with no later use)
+            for v, b in list(where_v.items()):
+                if b in set(W[n:n + nclob]):
+                    assert next_use(v, idx + 1) is None, (v, idx)
+                    where_v.pop(v)
+            for k, d in enumerate(results):
+                where_v[d] = W[n + k]
+
+        for idx, op in enumerate(ops):
+            kind = op[0]
+            if kind == "fp2mul":
+                _, d, a, b = op
+                call(idx, [a[0], a[1], b[0], b[1]], 3, [d[0], d[1]], "s[56:57]")
+            elif kind == "fp2sqr":
+                _, d, a = op
+                call(idx, [a[0], a[1]], 5, [d[0], d[1]], "s[58:59]")
+            elif kind == "lin":
+                _, lk, d, a, b = op
+                locked = {x for x in (a, b, d) if x is not None}
+                A = ensure_v(a, idx, locked)
+                Bk = ensure_v(b, idx, locked) if b is not None else None
+                pref = self.io_base + self.outputs[d] * L if d in self.outputs else None
+                fr = free_blocks()
+                if pref is not None and pref in fr:
+                    D = pref
+                elif next_use(a, idx + 1) is None and a not in where_a and (pref is None or where_v.get(a) == pref) \
+                        and not (idx <= exp_idx and where_v.get(a) in io_blocks):
+                    D = where_v.pop(a)
+                else:
+                    D = get_v(idx, locked, prefer=pref)
+                if idx <= exp_idx:
+                    assert D not in io_blocks
+                where_v[d] = D
+                self._emit_lin(lk, D, A, Bk)
+            elif kind == "norm":
+                blk = ensure_v(op[1], idx, {op[1]})
+                if idx <= exp_idx:
+                    assert blk not in io_blocks
+                self._emit_norm(blk)
+                if op[1] in where_a:
+                    afree.append(where_a.pop(op[1]))
+            elif kind == "export":
+                # H = U2 - X1 = 0 mod p (P = +-Q) is the case the generic formulas do not cover.  The 56-bit filter of
+                # gs_fq28.cuh (maybe_zero_limbs01: k = (V mod 2^56) p^-1 mod 2^56 is a SMALL signed integer when V = k p)
+                # on both coordinates of H, here: if ANY active lane may have H = 0, the subroutine returns at once with
+                # FLAG = 1 and every operand as it came (point in its I/O blocks, addend in its AGPR blocks), and the caller
+                # sends those lanes through the C++ addition.  False alarms 2^-35 per lane.  Nothing is live in the caller
+                # across the call but the two operands -- with the test outside, hipcc kept copies of both (140 registers)
+                # and spilled the table entry it had just requested for the next step.
+                # s[60:61] = p^-1 mod 2^56 (low 32, high 24 bits); temporaries: the accumulators, T, HOUT[0..3]
+                a = op[1]
+                b0, b1 = ensure_v(a[0], idx, set(a)), ensure_v(a[1], idx, set(a))
+                a0lo, a0hi = "v%d" % (7 * L), "v%d" % (7 * L + 1)
+                a1lo, a1hi = "v%d" % (7 * L + 2), "v%d" % (7 * L + 3)
+                T, H1 = self.t, self.hout[1]
+                o.append("s_mov_b32 s62, 0x10000000")
+                for c, blk in enumerate((b0, b1)):
+                    o.append("v_mov_b32 %s, %s" % (a0lo, self.vr(blk, 0)))
+                    o.append("v_ashrrev_i32 %s, 31, %s" % (a0hi, self.vr(blk, 0)))
+                    o.append("v_mad_i64_i32 %s, vcc, %s, s62, %s" % (self.acc[0], self.vr(blk, 1), self.acc[0]))
+                    o.append("v_mul_lo_u32 %s, %s, s61" % (T, a0lo))
+                    o.append("v_mul_lo_u32 %s, %s, s60" % (H1, a0hi))
+                    o.append("v_mad_u64_u32 %s, vcc, %s, s60, 0" % (self.acc[1], a0lo))
+                    o.append("v_add3_u32 %s, %s, %s, %s" % (a1hi, a1hi, T, H1))
+                    o.append("v_bfe_i32 %s, %s, 0, 24" % (a1hi, a1hi))
+                    o.append("v_add_co_u32 %s, vcc, 0x100000, %s" % (a1lo, a1lo))
+                    o.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (a1hi, a1hi))
+                    o.append("v_cmp_eq_u32 vcc, 0, %s" % a1hi)
+                    o.append("s_mov_b64 s[38:39], vcc" if c == 0 else "s_and_b64 s[38:39], s[38:39], vcc")
+                    o.append("v_cmp_ge_u32 vcc, 0x200000, %s" % a1lo)
+                    o.append("s_and_b64 s[38:39], s[38:39], vcc")
+                o.append("s_mov_b64 vcc, s[38:39]")
+                o.append("s_cbranch_vccz .Lgs_g2c_go%d_%%=" % L)
+                o.append("v_mov_b32 %s, 1" % self.hout[0])
+                o.append("s_setpc_b64 s[36:37]")
+                o.append(".Lgs_g2c_go%d_%%=:" % L)
+            else:
+                raise ValueError(kind)
+            drop_dead(idx + 1)
+        # outputs into their blocks (everything else is dead): misplaced ones sitting on another output's block step aside
+        drop_dead(final)
+        for v in self.outputs:
+            ensure_v(v, final, set(self.outputs))
+        targets = {self.io_base + k * L for k in self.outputs.values()}
+        misplaced = [v for v, k in self.outputs.items() if where_v[v] != self.io_base + k * L]
+        for v in misplaced:
+            if where_v[v] in targets:
+                spare = [b for b in free_blocks() if b not in targets]
+                assert spare, "no spare block for the final placement"
+                mov(spare[0], where_v[v])
+                where_v[v] = spare[0]
+        for v in misplaced:
+            want = self.io_base + self.outputs[v] * L
+            assert want in free_blocks(), (v, want)
+            mov(want, where_v[v])
+            where_v[v] = want
+        if exp_idx >= 0:
+            o.append("v_mov_b32 %s, 0" % self.hout[0])
+        o.append("s_setpc_b64 s[36:37]")
+
+
+_G2_CACHE = {}
+
+
+def _cached(fn):
+    def wrapper(L, cls=None):
+        key = (fn.__name__, L, cls)
+        if key not in _G2_CACHE:
+            _G2_CACHE[key] = fn(L, cls)
+        return _G2_CACHE[key]
+    wrapper.__name__ = fn.__name__
+    return wrapper
+
+
+@_cached
+def g2_dbl(L, cls=None):
+    p = (cls or Prog2)(L, 6)
     X, Y, Z = p.inp("X", 0), p.inp("Y", 1), p.inp("Z", 2)
     a = p.sqr("a", X)
     b = p.sqr("b", Y)
@@ -724,9 +1120,10 @@ def g2_dbl(L):
     return p
 
 
-def g2_madd(L):
-    p = Prog2(L, 10)
-    X, Y, Z, qx, qy = p.inp("X", 0), p.inp("Y", 1), p.inp("Z", 2), p.inp("qx", 3), p.inp("qy", 4)
+@_cached
+def g2_madd(L, cls=None):
+    p = (cls or Prog2)(L, 10)
+    X, Y, Z, qx, qy = p.inp("X", 0), p.inp("Y", 1), p.inp("Z", 2), p.inp_q("qx", 3, 0), p.inp_q("qy", 4, 1)
     z1z1 = p.sqr("z1z1", Z)
     u2 = p.mul("u2", qx, z1z1)
     t = p.mul("t", qy, Z)
@@ -752,10 +1149,99 @@ def g2_madd(L):
     return p
 
 
-def emit_g2(L):
+# ---- a tower program on the same machinery (round 4): the general Fp6 product ------------------------------------------
+# (L = 14 is BLS12-381: xi = 1 + u;  L = 10 is BN254: xi = 9 + u -- the wrappers static_assert it)
+def _mul_xi(p, name, a, L, normed_in):
+    """xi * a as Fq-level linear ops (gs_tower.cuh mul_xi): returns the new value (lazy)"""
+    d = p._n(name)
+    if L == 14:   # (1 + u)(a0 + a1 u) = (a0 - a1) + (a0 + a1) u
+        p.ops.append(("lin", "sub", d[0], a[0], a[1]))
+        p.ops.append(("lin", "add", d[1], a[0], a[1]))
+        return d
+    # (9 + u)(a0 + a1 u) = (9 a0 - a1) + (9 a1 + a0) u ; 8x is normalised on the way (input A <= 1.9)
+    e = p._n(name + "e")
+    for c in (0, 1):
+        p.ops.append(("lin", "x4", e[c], a[c], None))
+        p.ops.append(("norm", e[c]))
+        p.ops.append(("lin", "dbl", e[c] + "d", e[c], None))
+        p.ops.append(("norm", e[c] + "d"))
+    e8 = (e[0] + "d", e[1] + "d")
+    s0, s1 = name + "s.0", name + "s.1"
+    p.ops.append(("lin", "add", s0, e8[0], a[0]))
+    p.ops.append(("lin", "sub", d[0], s0, a[1]))
+    p.ops.append(("lin", "add", s1, e8[1], a[1]))
+    p.ops.append(("lin", "add", d[1], s1, a[0]))
+    return d
+
+
+@_cached
+def f6_mul(L, cls=None):
+    """gs_tower.cuh f6_mul, statement by statement: a (in/out VGPR blocks) *= b (AGPR blocks)"""
+    p = Prog2c(L, 6, 6)
+    a = [p.inp("a%d" % k, k) for k in range(3)]
+    b = [p.inp_q("b%d" % k, 0, k) for k in range(3)]
+    v0, v1, v2 = p.mul("v0", a[0], b[0]), p.mul("v1", a[1], b[1]), p.mul("v2", a[2], b[2])
+
+    def cross(nm, i, j, vi, vj):
+        sa, sb = p.lin("add", nm + "sa", a[i], a[j]), p.lin("add", nm + "sb", b[i], b[j])
+        m = p.mul(nm + "m", sa, sb)
+        return p.lin("sub", nm, p.lin("sub", nm + "x", m, vi), vj)
+    t0 = cross("t0", 1, 2, v1, v2)
+    t1 = cross("t1", 0, 1, v0, v1)
+    t2 = cross("t2", 0, 2, v0, v2)
+    if L != 14:
+        t0 = p.norm(t0)
+    r0 = p.norm(p.lin("add", "r0", v0, _mul_xi(p, "xt0", t0, L, L != 14)))
+    r1 = p.norm(p.lin("add", "r1", t1, _mul_xi(p, "xv2", v2, L, True)))
+    r2 = p.norm(p.lin("add", "r2", t2, v1))
+    p.outp(r0, 0), p.outp(r1, 1), p.outp(r2, 2)
+    p.compile()
+    return p
+
+
+# (Karabina's compressed squaring was generated too and dropped: its 22 carry rounds and 30 linear operations are ~1 640
+# instructions whichever compiler arranges them; with the ~40 block moves around its four calls the generated form came to
+# 2 180 instructions against the ~1 950 hipcc's loop body spends between the same calls, with no memory access in either.)
+
+
+def emit_tower(L):
+    """C++ wrapper of the tower subroutine (compact form only)"""
     NL = "\\n\\t"
     o = []
-    progs = {"dbl": g2_dbl(L), "madd": g2_madd(L)}
+    mod = ['"{s%d}"(C::P28[%d])' % (40 + i, i) for i in range(L)] + ['"{s%d}"(C::P28_INV)' % (40 + L)]
+    mod += ['"{s[56:57]}"((uint64_t)(uintptr_t)&gs_fp2mul28_sub_%d)' % L,
+            '"{s[58:59]}"((uint64_t)(uintptr_t)&gs_fp2sqr28_sub_%d)' % L]
+    stats = {}
+    for nm, prog, vnames, anames in (
+            ("f6mul", f6_mul(L), ["a00", "a01", "a10", "a11", "a20", "a21"], ["b00", "b01", "b10", "b11", "b20", "b21"]),):
+        sym = "gs_%s_sub_%d" % (nm, L)
+        o.append('extern "C" __device__ void %s();' % sym)
+        body = ["s_setpc_b64 s[30:31]", ".p2align 8", ".globl %s" % sym, ".type %s,@function" % sym, sym + ":"] + prog.out
+        o.append('extern "C" __device__ __attribute__((used, noinline)) void gs_%s_holder_%d() {' % (nm, L))
+        o.append('  asm volatile("%s" ::: "memory");' % NL.join(body))
+        o.append("}")
+        io = prog.io_base
+        ios = ['"+{v%d}"(%s[%d])' % (io + k * L + i, n_, i) for k, n_ in enumerate(vnames) for i in range(L)]
+        ios += ['"+{a%d}"(%s[%d])' % (prog.ain_base + k * L + i, n_, i) for k, n_ in enumerate(anames) for i in range(L)]
+        work = ['"v%d"' % r for r in range(0, 7 * L + 4)] + ['"%s"' % prog.t] + ['"s36"', '"s37"']
+        park = ['"a%d"' % r for r in range(Prog2c.NPARK * L)]
+        sig = ", ".join("int32_t (&%s)[%d]" % (n_, L) for n_ in vnames + anames)
+        o.append("template <class C> __device__ __forceinline__ void %s_call_%d(%s) {" % (nm, L, sig))
+        o.append("  static_assert(C::XI_A == %d, \"the generated tower code is per (limb count, xi)\");" % (1 if L == 14 else 9))
+        o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (len(ios) + len(mod)))
+        o.append("      : %s" % ", ".join(ios))
+        o.append("      : %s" % ", ".join(mod + ['"s"((uint64_t)(uintptr_t)&%s)' % sym]))
+        o.append("      : %s);" % ", ".join(work + park + ['"vcc"', '"s34"', '"s35"']))
+        o.append("}")
+        stats[nm] = (len(prog.out), prog.stats["park"], prog.stats["unpark"], prog.stats["mov"], prog.stats["calls"])
+    return "\n".join(o), stats
+
+
+def emit_g2(L, cls=None):
+    NL = "\\n\\t"
+    o = []
+    compact = cls is Prog2c
+    progs = {"dbl": g2_dbl(L, cls), "madd": g2_madd(L, cls)}
     # (the code is longer than the +-128 KB reach of s_branch: the never-executed holders return instead of jumping
     # over it, one holder per subroutine)
     for nm, p in progs.items():
@@ -766,10 +1252,16 @@ def emit_g2(L):
         o.append('  asm volatile("%s" ::: "memory");' % NL.join(body))
         o.append("}")
     mod = ['"{s%d}"(C::P28[%d])' % (40 + i, i) for i in range(L)] + ['"{s%d}"(C::P28_INV)' % (40 + L)]
+    if compact:  # the shared multiplier subroutines' addresses, where the generated code expects them
+        mod += ['"{s[56:57]}"((uint64_t)(uintptr_t)&gs_fp2mul28_sub_%d)' % L,
+                '"{s[58:59]}"((uint64_t)(uintptr_t)&gs_fp2sqr28_sub_%d)' % L]
     pm = progs["madd"]
     io = pm.io_base
     work = ['"v%d"' % r for r in range(0, 7 * L + 4)] + ['"%s"' % pm.t]
-    park = ['"a%d"' % r for r in range(Prog2.NPARK * L)]
+    if compact:
+        work += ['"s36"', '"s37"', '"s38"', '"s39"', '"s62"'] + ['"%s"' % h for h in pm.hout[1:]]
+        mod += ['"{s60}"((uint32_t)(pinv56<C>() & 0xffffffffu))', '"{s61}"((uint32_t)(pinv56<C>() >> 32))']
+    park = ['"a%d"' % r for r in range((Prog2c if compact else Prog2).NPARK * L)]
     names6 = ("x0", "x1", "y0", "y1", "z0", "z1")
     names10 = names6 + ("qx0", "qx1", "qy0", "qy1")
     sig = lambda names: ", ".join("int32_t (&%s)[%d]" % (n, L) for n in names)
@@ -782,9 +1274,17 @@ def emit_g2(L):
     o.append("      : %s);" % ", ".join(work + park + ['"vcc"', '"s34"', '"s35"']))
     o.append("}")
     # mixed addition
-    ios = ['"+{v%d}"(%s[%d])' % (io + k * L + i, nm, i) for k, nm in enumerate(names10) for i in range(L)]
-    ios += ['"={%s}"(h[%d])' % (pm.hout[i], i) for i in range(4)]
-    o.append("template <class C> __device__ __forceinline__ void g2_madd_call_%d(%s, int32_t (&h)[4]) {" % (L, sig(names10)))
+    if compact:  # the addend arrives in the four AGPR blocks after the parking space (and is destroyed)
+        ios = ['"+{v%d}"(%s[%d])' % (io + k * L + i, nm, i) for k, nm in enumerate(names6) for i in range(L)]
+        ios += ['"+{a%d}"(%s[%d])' % (pm.ain_base + k * L + i, nm, i) for k, nm in enumerate(names10[6:]) for i in range(L)]
+    else:
+        ios = ['"+{v%d}"(%s[%d])' % (io + k * L + i, nm, i) for k, nm in enumerate(names10) for i in range(L)]
+    if compact:  # FLAG: 1 = "some lane may have H = 0: nothing was touched, take the C++ addition"
+        ios += ['"={%s}"(flag)' % pm.hout[0]]
+        o.append("template <class C> __device__ __forceinline__ void g2_madd_call_%d(%s, int32_t& flag) {" % (L, sig(names10)))
+    else:
+        ios += ['"={%s}"(h[%d])' % (pm.hout[i], i) for i in range(4)]
+        o.append("template <class C> __device__ __forceinline__ void g2_madd_call_%d(%s, int32_t (&h)[4]) {" % (L, sig(names10)))
     o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (len(ios) + len(mod)))
     o.append("      : %s" % ", ".join(ios))
     o.append("      : %s" % ", ".join(mod + ['"s"((uint64_t)(uintptr_t)&gs_g2_madd_sub_%d)' % L]))
@@ -806,9 +1306,21 @@ def main():
         o.append("// ---- G2 point operations as subroutines, L = %d: %s" % (
             L, ", ".join("%s %d instructions (%d blocks parked in AGPRs, %d fetched back, %d moved at the end)"
                          % (k, v[0], v[1], v[2], v[3]) for k, v in stats.items())))
-        o.append("#if defined(GS_POINT_ASM_G2)  // measured and not shipped: see gs_curve.cuh (instruction-cache bound)")
+        o.append("#if defined(GS_POINT_ASM_G2_STRAIGHT)  // measured and not shipped: see gs_curve.cuh (instruction-cache bound)")
+        o.append(src)
+        src, stats = emit_g2(L, Prog2c)
+        o.append("#elif defined(GS_POINT_ASM_G2)")
+        o.append("// ---- G2 point operations, compact form (calls of the shared Fp2 subroutines), L = %d: %s" % (
+            L, ", ".join("%s %d instructions of glue (%d parked, %d fetched back, %d block moves)"
+                         % (k, v[0], v[1], v[2], v[3]) for k, v in stats.items())))
         o.append(src)
         o.append("#endif")
+        src, stats = emit_tower(L)
+        o.append("// ---- tower operations as subroutines (compact form), L = %d: %s" % (
+            L, ", ".join("%s %d instructions of glue around %d calls (%d parked, %d fetched back, %d block moves)"
+                         % (k, v[0], v[4], v[1], v[2], v[3]) for k, v in stats.items())))
+        o.append("#define GS_TOWER_ASM 1")
+        o.append(src)
     with open(os.path.join(here, "gs_pointops_asm.h"), "w") as f:
         f.write("\n".join(o) + "\n")
     print("wrote gs_pointops_asm.h")

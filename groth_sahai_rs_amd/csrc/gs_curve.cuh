@@ -172,13 +172,41 @@ template <class C> GS_HD void jac_madd_ip(Jac<Fq<C>>& r, const Aff<Fq<C>>& q) {
     r = tr;
   }
 }
-#if defined(GS_POINT_ASM_G2)
+#if defined(GS_POINT_ASM_G2) && !defined(GS_POINT_ASM_G2_STRAIGHT)
+// G2, compact form (gen_pointops_asm.py, Prog2c): the subroutine owns the data movement around the SHARED Fp2 multiplier
+// subroutines, parks what does not fit in AGPRs, takes the addend in AGPRs and tests H = 0 itself -- it returns at once
+// with flag = 1 and both operands untouched when any lane may have P = +-Q, so NOTHING but the two operands is live here
+// across the call (copies of both kept for a test after the call cost hipcc the registers of the table entry it had just
+// requested for the next step: k_fix.g2 12.3 -> 14.7 ms with the test outside).
+template <class C> GS_HD void jac_dbl_ip(Jac<Fp2<C>>& r) {
+  if constexpr (C::L == 14)
+    g2_dbl_call_14<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v);
+  else
+    g2_dbl_call_10<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v);
+}
+template <class C> GS_HD void jac_madd_ip(Jac<Fp2<C>>& r, const Aff<Fp2<C>>& q) {
+  Aff<Fp2<C>> qq = q;
+  int32_t flag = 1;  // lanes that skip the call (either operand the identity) take the C++ addition as well
+  if (!(aff_is_inf(q) || is_zero_limbs(r.z))) {
+    if constexpr (C::L == 14)
+      g2_madd_call_14<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v, qq.x.c0.v, qq.x.c1.v, qq.y.c0.v, qq.y.c1.v, flag);
+    else
+      g2_madd_call_10<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v, qq.x.c0.v, qq.x.c1.v, qq.y.c0.v, qq.y.c1.v, flag);
+  }
+  if (flag) {  // rare: first addition of a lane, identity table entries, P = +-Q (false alarms 2^-35 per lane)
+    Jac<Fp2<C>> tp = r, tr;
+    Aff<Fp2<C>> tq = qq;
+    jac_madd_edge(tr, tp, tq);
+    r = tr;
+  }
+}
+#elif defined(GS_POINT_ASM_G2_STRAIGHT)
 // G2: the same, the subroutines park what does not fit 256 VGPRs in AGPRs themselves (gen_pointops_asm.py, Prog2).
 // MEASURED AND NOT SHIPPED (round 4, gpurun_out r4e / r4f on 2^16 PPE): bit-exact on every forced shape, but
 // k_var_multi8w5x2.g2 40.0 -> 41.5 ms and k_fix.g2 12.2 -> 17.8 ms.  The straight-line G2 addition is 114 KB of code
 // and the doubling 68 KB -- against a 64 KB instruction cache shared by two CUs -- while hipcc's version keeps
 // calling the SAME 10.6 KB Fp2 multiplier: fewer instructions (14.2 k against ~17 k per addition) lose to instruction
-// fetch.  The G1 pair (42 + 26 KB) stays on the winning side (-11..13 %).  -DGS_POINT_ASM_G2 brings this back.
+// fetch.  The G1 pair (42 + 26 KB) stays on the winning side (-11..13 %).  -DGS_POINT_ASM_G2_STRAIGHT brings this back.
 template <class C> GS_HD void jac_dbl_ip(Jac<Fp2<C>>& r) {
   if constexpr (C::L == 14)
     g2_dbl_call_14<C>(r.x.c0.v, r.x.c1.v, r.y.c0.v, r.y.c1.v, r.z.c0.v, r.z.c1.v);

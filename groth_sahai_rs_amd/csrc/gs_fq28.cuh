@@ -55,6 +55,10 @@ template <class C> struct Fq28 {
 #if !defined(GS_NO_ASM_CALL) && !defined(GS_NO_POINT_ASM)
 // whole G1 point operations as subroutines with their own register allocation (gen_pointops_asm.py; used by gs_curve.cuh)
 #define GS_POINT_ASM 1
+#if !defined(GS_NO_POINT_ASM_G2) && !defined(GS_POINT_ASM_G2_STRAIGHT) && !defined(GS_POINT_ASM_G2)
+#define GS_POINT_ASM_G2 1  // G2 too: the compact form (generated data movement around the shared Fp2 subroutines)
+#endif
+template <class C> constexpr uint64_t pinv56();  // (below; the G2 subroutines take it in s[60:61])
 #include "gs_pointops_asm.h"
 #endif
 #endif

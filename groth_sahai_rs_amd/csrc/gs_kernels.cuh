@@ -952,9 +952,12 @@ struct k_final {
   size_t e = g >> 2;
   int c = (int)(g & 3);
   Fp12<C> f;
+  unsigned long long sf0 = GS_STAMP_T();
   cell_product(f, mpart, e, ntask, c, cm);
+  unsigned long long sf1 = GS_STAMP_T();
   Fp12<C> r;
   final_exp(r, f);
+  unsigned long long sf2 = GS_STAMP_T();
   bool ok;
   if (c == 3 && target) {
     Fp12<C> t;
@@ -964,6 +967,10 @@ struct k_final {
     ok = f12_is_one(r);
   }
   cellok[g] = ok ? 1 : 0;
+  GS_STAMP_ADD(6, sf1 - sf0);
+  GS_STAMP_ADD(7, sf2 - sf1);
+  GS_STAMP_ADD(8, GS_STAMP_T() - sf2);
+  GS_STAMP_ADD(9, 1);
 }
 };
 

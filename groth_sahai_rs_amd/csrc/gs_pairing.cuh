@@ -534,6 +534,7 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x_karabina(Fp12<C>& r, const F
   int top = 63;
   while (!((C::X_ABS >> top) & 1)) top--;
   int ns = 0, since = 0;
+  unsigned long long sk0 = GS_STAMP_T();
 #pragma unroll 1
   for (int i = 1; i <= top; i++) {
     cyclo_sqr_compressed<C>(g2, g3, g4, g5);
@@ -552,6 +553,8 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x_karabina(Fp12<C>& r, const F
     }
   }
   // 1 / (4 z2) for all saved values behind one inversion
+  unsigned long long sk1 = GS_STAMP_T();
+  GS_STAMP_ADD(10, sk1 - sk0);  // diagnosis build: the chain of compressed squarings
   Fp2<C> den[NS], pre[NS];
   Fp2<C> acc = one_of<Fp2<C>>();
   bool degenerate = false;
@@ -566,6 +569,7 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x_karabina(Fp12<C>& r, const F
     return;
   }
   Fp2<C> suf = inv(acc);
+  GS_STAMP_ADD(11, GS_STAMP_T() - sk1);  // prefix products + the shared inversion
   Fp12<C> out;
   bool have = false;
   if (C::X_ABS & 1) {
@@ -595,6 +599,7 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x_karabina(Fp12<C>& r, const F
   }
   if (C::X_NEG) f12_conj(out, out);
   r = out;
+  GS_STAMP_ADD(12, GS_STAMP_T() - sk0);  // the whole x-power
 }
 template <class C> GS_HD void f12_exp_by_x(Fp12<C>& r, const Fp12<C>& f) {
 #if !defined(GS_NO_KARABINA)
@@ -613,12 +618,14 @@ template <class C> struct ExpXLane {
 };
 template <class C, class EX> GS_HD_NOINLINE void final_exp_with(Fp12<C>& out, const Fp12<C>& f, EX& ex) {
   Fp12<C> r, t, y0, y1, y2;
+  unsigned long long se0 = GS_STAMP_T();
   // easy part: f^((p^6-1)(p^2+1))
   f12_inv(t, f);
   f12_conj(r, f);
   f12_mul(r, r, t);
   f12_frob(t, r, 2);
   f12_mul(r, r, t);
+  GS_STAMP_ADD(13, GS_STAMP_T() - se0);  // easy part
   if (!C::IS_BN) {
     // hard part, eprint 2020/875 (Hayashida-Hayasaka-Teruya): exponent
     // (x-1)^2 (x+p) (x^2+p^2-1) + 3

@@ -21,6 +21,10 @@ spec = importlib.util.spec_from_file_location("gen_pointops_asm",
                                               os.path.join(REPO, "groth_sahai_rs_amd", "csrc", "gen_pointops_asm.py"))
 gen = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(gen)
+spec2 = importlib.util.spec_from_file_location("gen_mul28_asm",
+                                               os.path.join(REPO, "groth_sahai_rs_amd", "csrc", "gen_mul28_asm.py"))
+mulgen = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(mulgen)
 
 M = (1 << 28) - 1
 
@@ -180,6 +184,10 @@ class Machine:
 
     def __init__(self, p, L):
         self.v, self.a, self.s = {}, {}, {}
+        self.L = L
+        self.vcc, self.sflag = False, {}
+        pinv56 = pow(p, -1, 1 << 56)
+        self.s[60], self.s[61] = pinv56 & 0xFFFFFFFF, pinv56 >> 32  # (the compact G2 addition's H = 0 filter)
         P28 = to_limbs(p, L)
         for i, x in enumerate(P28):
             self.s[40 + i] = x
@@ -214,9 +222,45 @@ class Machine:
         return u - (1 << 64) if u >> 63 else u
 
     def run(self, prog):
-        for ins in prog:
-            ins = ins.strip()
-            if ins.startswith(".") or ins.startswith("s_setpc"):
+        prog = [x.strip() for x in prog]
+        labels = {x[:-1]: i for i, x in enumerate(prog) if x.endswith(":")}
+        pc = -1
+        while pc + 1 < len(prog):
+            pc += 1
+            ins = prog[pc]
+            if ins.startswith("s_setpc"):
+                return
+            if ins.startswith(".") or ins.startswith("s_mov_b64 s[36:37]"):
+                continue
+            if ins.startswith("s_cbranch_vccz"):
+                if not self.vcc:
+                    pc = labels[ins.split()[1]]
+                continue
+            if ins.startswith("s_mov_b64") or ins.startswith("s_and_b64"):
+                op, rest = ins.split(None, 1)
+                a = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)]
+                val = lambda t: self.vcc if t == "vcc" else self.sflag[t]
+                r = val(a[1]) if op == "s_mov_b64" else (val(a[1]) and val(a[2]))
+                if a[0] == "vcc":
+                    self.vcc = r
+                else:
+                    self.sflag[a[0]] = r
+                continue
+            if ins.startswith("s_swappc_b64"):
+                # the compact G2 form calls the SHARED multiplier subroutines of gs_mul28_asm.h: run their generated
+                # bodies, then forget what they are declared to destroy (a read of a destroyed register is a KeyError)
+                L = self.L
+                tgt = ins.split(",")[1].strip()
+                if tgt == "s[56:57]":
+                    self.run(mulgen.sub_body_fp2(L))
+                    gone = list(range(6 * L, 7 * L + 4))
+                else:
+                    assert tgt == "s[58:59]", ins
+                    self.run(mulgen.sub_body_fp2sqr(L))
+                    gone = list(range(4 * L, 7 * L + 4))
+                for k in gone:
+                    self.v.pop(k, None)
+                self.calls = getattr(self, "calls", 0) + 1
                 continue
             op, rest = ins.split(None, 1)
             args = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)]
@@ -262,6 +306,27 @@ class Machine:
                 r = (self.s32(self.rd(x)) << int(sh)) + self.s32(self.rd(y))
                 assert -(1 << 31) <= r < (1 << 31)
                 self.v[int(d[1:])] = r
+            elif op == "s_mov_b32":
+                d, x = args
+                self.s[int(d[1:])] = int(x, 0)
+            elif op == "v_bfe_i32":
+                d, x, off, w = args
+                val_ = (self.rd(x) & 0xFFFFFFFF) >> int(off) & ((1 << int(w)) - 1)
+                self.v[int(d[1:])] = val_ - (1 << int(w)) if val_ >> (int(w) - 1) else val_
+            elif op == "v_add3_u32":
+                d, x, y, z = args
+                self.v[int(d[1:])] = self.s32(self.rd(x) + self.rd(y) + self.rd(z))  # (wraps by design: low 64 bits of a product)
+            elif op in ("v_add_co_u32", "v_addc_co_u32"):
+                d, _vcc, x, y = args[:4]
+                t = (self.rd(x) & 0xFFFFFFFF) + (self.rd(y) & 0xFFFFFFFF) + (int(self.vcc) if op == "v_addc_co_u32" else 0)
+                self.vcc = bool(t >> 32)
+                self.v[int(d[1:])] = self.s32(t)
+            elif op == "v_cmp_eq_u32":
+                _vcc, x, y = args
+                self.vcc = (self.rd(x) & 0xFFFFFFFF) == (self.rd(y) & 0xFFFFFFFF)
+            elif op == "v_cmp_ge_u32":
+                _vcc, x, y = args
+                self.vcc = (self.rd(x) & 0xFFFFFFFF) >= (self.rd(y) & 0xFFFFFFFF)
             else:
                 raise AssertionError("opcode not modelled: " + ins)
 
@@ -343,37 +408,110 @@ def jac2_madd(p, X, Y, Z, x2, y2):
     return x3, y3, f2(p, "sub", f2(p, "sub", f2mul(p, zh, zh), z1z1), hh)
 
 
+@pytest.mark.parametrize("form", ["straight", "compact"])
 @pytest.mark.parametrize("cname,L", [("bls12_381", 14), ("bn254", 10)])
-def test_emitted_g2_instructions(cname, L):
-    """The G2 subroutines park values in AGPRs by a farthest-next-use allocator: run the emitted code itself."""
+def test_emitted_g2_instructions(cname, L, form):
+    """The G2 subroutines park values in AGPRs by a farthest-next-use allocator: run the emitted code itself.  `compact`
+    is the form that calls the shared Fp2 multiplier subroutines (Prog2c)."""
     c = curve(cname)
     p = c.p
     rnd = random.Random(99 + L)
+    cls = gen.Prog2c if form == "compact" else gen.Prog2
     for it in range(5):
         e = Emu(p, L)
         vals = [(rnd.randrange(p), rnd.randrange(p)) for _ in range(5)]
         if it == 0:
             vals[2] = (0, 0)  # the identity stays the identity under doubling
         for fn, nin, ref in ((gen.g2_dbl, 3, jac2_dbl), (gen.g2_madd, 5, jac2_madd)):
-            prog = fn(L)
+            prog = fn(L, cls)
             use = list(vals[:nin])
             if fn is gen.g2_madd and use[2] == (0, 0):
                 use[2] = (1, 0)
             m = Machine(p, L)
             for k, (c0, c1) in enumerate(use):
+                if form == "compact" and k >= 3:  # the addend arrives in AGPRs (after the parking blocks)
+                    for q, cc in enumerate((c0, c1)):
+                        for i, x in enumerate(e.enc(cc)):
+                            m.a[prog.ain_base + (2 * (k - 3) + q) * L + i] = x
+                    continue
                 _put(m, prog.io_base + 2 * k * L, e.enc(c0))
                 _put(m, prog.io_base + (2 * k + 1) * L, e.enc(c1))
             m.run(prog.out)
             got = tuple((e.fe(_get(m, prog.io_base + 2 * k * L, L)), e.fe(_get(m, prog.io_base + (2 * k + 1) * L, L)))
                         for k in range(3))
             assert got == ref(p, *use), (cname, fn.__name__, it)
+            if form == "compact" and fn is gen.g2_madd:
+                assert m.v[int(prog.hout[0][1:])] == 0  # flag: the generic formulas applied
+                # P = +-Q (H = 0 mod p): the subroutine returns at once, flag = 1, operands untouched
+                X, Y, Z, x2, y2 = use
+                zz = f2mul(p, Z, Z)
+                zinv = pow((zz[0] * zz[0] + zz[1] * zz[1]) % p, -1, p)
+                x2e = f2mul(p, X, (zz[0] * zinv % p, -zz[1] * zinv % p))  # x2 = X / Z^2
+                m2 = Machine(p, L)
+                for k, (c0, c1) in enumerate((X, Y, Z)):
+                    _put(m2, prog.io_base + 2 * k * L, e.enc(c0))
+                    _put(m2, prog.io_base + (2 * k + 1) * L, e.enc(c1))
+                for k, (c0, c1) in enumerate((x2e, y2)):
+                    for q, cc in enumerate((c0, c1)):
+                        for i, x in enumerate(e.enc(cc)):
+                            m2.a[prog.ain_base + (2 * k + q) * L + i] = x
+                before_v = {k: v_ for k, v_ in m2.v.items()}
+                before_a = dict(m2.a)
+                m2.run(prog.out)
+                assert m2.v[int(prog.hout[0][1:])] == 1
+                assert all(m2.v[k] == v_ for k, v_ in before_v.items())
+                assert all(m2.a[k] == v_ for k, v_ in before_a.items())
             if fn is gen.g2_dbl and use[2] == (0, 0):
                 assert _get(m, prog.io_base + 4 * L, L) == [0] * L and _get(m, prog.io_base + 5 * L, L) == [0] * L
             # nothing outside the declared registers was written
             hi = max(k for k in m.v)
             assert hi < prog.top, hi
-            assert all(k < Prog2_NPARK_L(prog) for k in m.a)
+            assert all(k < Prog2_NPARK_L(prog) + (4 * L if form == "compact" else 0) for k in m.a)
 
 
 def Prog2_NPARK_L(prog):
     return prog.NPARK * prog.L
+
+
+def f6mul_ref(p, xi, a, b):
+    """(a0 + a1 v + a2 v^2)(b0 + b1 v + b2 v^2) with v^3 = xi, coefficients in Fp2 = Fp[u]/(u^2 + 1)"""
+    def add(x, y):
+        return ((x[0] + y[0]) % p, (x[1] + y[1]) % p)
+    mx = lambda x: f2mul(p, x, xi)
+    m = lambda i, j: f2mul(p, a[i], b[j])
+    r0 = add(m(0, 0), mx(add(m(1, 2), m(2, 1))))
+    r1 = add(add(m(0, 1), m(1, 0)), mx(m(2, 2)))
+    r2 = add(add(m(0, 2), m(1, 1)), m(2, 0))
+    return r0, r1, r2
+
+
+@pytest.mark.parametrize("cname,L,xi", [("bls12_381", 14, (1, 1)), ("bn254", 10, (9, 1))])
+def test_emitted_f6_mul(cname, L, xi):
+    """The general Fp6 product as a generated subroutine (six nested calls of the shared Fp2 product): a in/out in VGPR
+    blocks, b in AGPR blocks; the emitted instructions against plain modular arithmetic."""
+    c = curve(cname)
+    p = c.p
+    rnd = random.Random(5 + L)
+    prog = gen.f6_mul(L)
+    for it in range(6):
+        e = Emu(p, L)
+        a = [(rnd.randrange(p), rnd.randrange(p)) for _ in range(3)]
+        b = [(rnd.randrange(p), rnd.randrange(p)) for _ in range(3)]
+        if it == 0:
+            a[1], b[2] = (0, 0), (p - 1, 0)
+        m = Machine(p, L)
+        for k in range(3):
+            for q in range(2):
+                _put(m, prog.io_base + (2 * k + q) * L, e.enc(a[k][q]))
+                for i, x in enumerate(e.enc(b[k][q])):
+                    m.a[prog.ain_base + (2 * k + q) * L + i] = x
+        m.run(prog.out)
+        got = tuple((e.fe(_get(m, prog.io_base + 2 * k * L, L)), e.fe(_get(m, prog.io_base + (2 * k + 1) * L, L)))
+                    for k in range(3))
+        assert got == f6mul_ref(p, xi, a, b), (cname, it)
+        assert m.calls == 6
+        assert max(m.v) < prog.top and max(m.a) < (prog.NPARK + 6) * L
+        # outputs are weakly normalised limbs (the contract every consumer of an Fp6 product relies on)
+        for k in range(6):
+            limbs = _get(m, prog.io_base + k * L, L)
+            assert all(0 <= x < (1 << 28) + 64 for x in limbs[:-1]), limbs

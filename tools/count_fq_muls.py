@@ -1,5 +1,5 @@
 """Fq multiplications per device primitive, counted by the CPU twin (the device headers compiled for the host with
--DGS_FQ28_CHECK, whose mul() increments a counter).  Output: profiles/r3/fq_mul_counts.json, read by bench.py to turn
+-DGS_FQ28_CHECK, whose mul() increments a counter).  Output: profiles/r4/fq_mul_counts.json (latest round), read by bench.py to turn
 the per-kernel work items reported by gs_prof_get_work into "useful Fq multiplications per step" (ALU roofline).
 A second counter gives the multiply-add INSTRUCTIONS the device kernels execute for the same primitive (static counts
 of the generated multiplier kernels: a squaring is 301 mads, not the 392 of the product it is credited as): the
@@ -79,6 +79,6 @@ for name in ("bls12_381", "bn254"):
     rng.bit_generator.state = state  # the same scalars for the second pass
     MADS[0] = True
     out[name]["executed_mads"] = table()
-path = os.path.join(ROOT, "profiles", "r3", "fq_mul_counts.json")
+path = os.path.join(ROOT, "profiles", "r4", "fq_mul_counts.json")
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
