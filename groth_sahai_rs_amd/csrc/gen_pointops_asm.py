@@ -1315,6 +1315,8 @@ def main():
                          % (k, v[0], v[1], v[2], v[3]) for k, v in stats.items())))
         o.append(src)
         o.append("#endif")
+        if not os.environ.get("GS_TOWER_ASM_EMIT"):   # measured and not shipped (gs_tower.cuh: f12_mul)
+            continue
         src, stats = emit_tower(L)
         o.append("// ---- tower operations as subroutines (compact form), L = %d: %s" % (
             L, ", ".join("%s %d instructions of glue around %d calls (%d parked, %d fetched back, %d block moves)"

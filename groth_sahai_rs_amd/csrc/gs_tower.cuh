@@ -250,6 +250,12 @@ template <class C> GS_HD void f12_mul_inl(Fp12<C>& r, const Fp12<C>& a, const Fp
   f6_mul_v(t1, t1);
   f6_addn(r.c0, t0, t1);
 }
+// (Round 4, measured and not kept: the out-of-line product as three calls of a GENERATED Fp6 product -- gen_pointops_asm.py
+// f6_mul: six nested calls of the shared Fp2 product with its own data movement, `a` in/out in VGPRs, `b` in AGPRs; the
+// emitted code is checked by tests/test_pointops_gen.py.  k_final 36.3 -> 37.1 ms: hipcc's marshalling of 18 blocks per
+// call and the ~590 callee-saved registers an out-of-line function must save around subroutines that clobber v0..v190 and
+// a0..a195 cost more than the spills they replace.  GS_TOWER_ASM_EMIT=1 in the generator's environment brings the
+// subroutine back.)
 template <class C> GS_HD_NOINLINE void f12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) { f12_mul_inl(r, a, b); }
 // complex squaring: 2 Fp6 multiplications
 template <class C> GS_ML void f12_sqr(Fp12<C>& r, const Fp12<C>& a) {
