@@ -591,7 +591,13 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x_karabina(Fp12<C>& r, const F
     Fp12<C> v;
     v.c0.c0 = z0, v.c1.c1 = z1, v.c1.c0 = z2, v.c0.c2 = z3, v.c0.c1 = z4, v.c1.c2 = z5;
     if (have) {
-      f12_mul(out, out, v);
+      // INLINE at this one site: every call of the out-of-line f12_mul saves and restores the ~420 callee-saved registers
+      // the product clobbers, a dword at a time -- a third of k_final's private-segment traffic, and the product phases
+      // of this kernel run at the HBM rate of that traffic (PMC: 16 % of its wave cycles in s_waitcnt).  Inline the
+      // product spills only what is live: k_final 36.5 -> 34.1 ms (profiles/r4/ab_fe_inline_*.json).  The same for the
+      // 11 products of final_exp_with needs them at ONE site too -- a table-driven loop over a register file of Fp12
+      // values, built and measured: 34.8 ms, the dynamic indexing costs more than the 11 register saves (not kept).
+      f12_mul_inl(out, out, v);
     } else {
       out = v;
       have = true;
