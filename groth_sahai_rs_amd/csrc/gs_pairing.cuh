@@ -478,7 +478,10 @@ template <class C> GS_HD_NOINLINE void f12_exp_by_x_gs(Fp12<C>& r, const Fp12<C>
     // full multiplication contracts them again, otherwise reduce every 3rd step
     if ((C::X_ABS >> i) & 1) {
       // `acc` must not have its address taken anywhere in this loop: it then lives in registers (AGPRs) from one
-      // squaring to the next instead of crossing memory twice per step (k_final 54.9 -> 44.5 ms at 2^16)
+      // squaring to the next instead of crossing memory twice per step (k_final 54.9 -> 44.5 ms at 2^16).  (The product
+      // INLINE here, as in f12_exp_by_x_karabina, was measured in round 4 and LOST on BN254 -- k_final 28.1 -> 31.9 ms:
+      // with the product's 18 multiplier calls in the loop body the accumulator no longer stays in registers across the
+      // squarings, which costs more than the register saves of 26 calls.)
       Fp12<C> t = acc;
       f12_mul(t, t, f);
       acc = t;
