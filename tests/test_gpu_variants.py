@@ -7,6 +7,7 @@ the small-batch shapes; here every shape is FORCED through gs_set_option, all fo
 equation of the batch bit-exact (commitments, pi, theta) and verdict-exact against oracle/gs_ref.c, and the library's
 kernel profile proves that the intended kernel is the one that ran.  Reference: src/prover/prove.rs:92-171,
 src/verifier.rs:23-55."""
+import numpy as np
 import pytest
 
 from gpubatch import run_batch
@@ -122,4 +123,58 @@ def test_option_values_are_validated():
                           ("var_w2", -1), ("endo", 0), ("endo", 1)):
             eng.set_option(key, good)
     finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("bn254", 1)])
+@pytest.mark.parametrize("shape", ["pair12_straus8x2w5_lane", "twin2_straus4x4_coop_notab", "single1_plain_coop_notab_overlap"])
+def test_identical_terms_in_one_lane_take_the_doubling_path(cname, cid, shape):
+    """P = Q inside a generated addition.  The G1 / G2 point-operation subroutines (gen_pointops_asm.py) are the generic
+    branch of the formulas; H = 0 (P = +-Q) is found by the 56-bit filter -- for G2 INSIDE the subroutine, which then
+    returns at once with every operand untouched and sends the whole wave through the C++ addition.  Random batches never
+    get there.  Here every equation carries two identical variables on both sides (X1 = X0, Y1 = Y0) and a Gamma of
+    ones, so that the Straus lanes of the prover (two identical (base, scalar) terms in one lane: the second addition of
+    the top window adds a point to itself) and, with one term per lane, the reductions meet P = Q; proofs and verdicts
+    against the C oracle, all four types."""
+    import torch
+
+    import groth_sahai_rs_amd as gs
+    import gs_ref_py as ref
+    from groth_sahai_rs_amd.workload import CURVES, Workload
+
+    o = SHAPES[shape]
+    for ty in (0, 1, 2, 3):
+        eng = gs.Engine(cid, 0)
+        for k, v in o.items():
+            eng.set_option(k, v)
+        m, n, N = 4, 4, 66
+        wl = Workload(eng, ty=ty, N=N, m=m, n=n, seed=777 + ty, corrupt_every=0)
+        sh = wl.sh
+        kx, ky, sx, sy, st = sh["kx"], sh["ky"], sh["sx"], sh["sy"], sh["st"]
+        r = CURVES[cid]["r"]
+        one = torch.from_numpy(np.array([((1 << 256) % r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)],
+                                        dtype=np.uint64).view(np.uint8).copy()).to(wl.X.device)
+        X, Y, G = wl.X.view(N, m, sx), wl.Y.view(N, n, sy), wl.Gamma.view(N, m * n, 32)
+        X[:, 1] = X[:, 0]
+        X[:, 3] = X[:, 2]
+        Y[:, 1] = Y[:, 0]
+        Y[:, 3] = Y[:, 2]
+        G[:, :] = one
+        wl.prove()
+        wl.verify()
+        eng.sync()
+        host = lambda t: t.cpu().numpy()
+        Xh, Yh, A, B, Gh, R, S, T = map(host, (wl.X, wl.Y, wl.A, wl.B, wl.Gamma, wl.R, wl.S, wl.T))
+        xc, yc, pi, th, tgt, ok = map(host, (wl.xcoms, wl.ycoms, wl.pi, wl.theta, wl.target, wl.ok))
+        cut = lambda a, e, sz: a[e * sz:(e + 1) * sz]
+        for e in (0, 1, 31, 64, 65):
+            out = ref.commit_and_prove(cname, ty, m, n, cut(Xh, e, m * sx), cut(Yh, e, n * sy), cut(A, e, n * sx),
+                                       cut(B, e, m * sy), cut(Gh, e, m * n * 32), cut(R, e, m * kx * 32),
+                                       cut(S, e, n * ky * 32), cut(T, e, ky * kx * 32), wl.crs)
+            for name, got, per in (("xcoms", xc, m * eng.COM1), ("ycoms", yc, n * eng.COM2), ("pi", pi, kx * eng.COM2),
+                                   ("theta", th, ky * eng.COM1)):
+                assert (out[name] == cut(got, e, per)).all(), (cname, shape, ty, e, name)
+            want = ref.verify(cname, ty, m, n, cut(A, e, n * sx), cut(B, e, m * sy), cut(Gh, e, m * n * 32),
+                              cut(tgt, e, st), out["xcoms"], out["ycoms"], out["pi"], out["theta"], wl.crs)
+            assert int(ok[e]) == want, (cname, shape, ty, e, "verdict")
         eng.close()
