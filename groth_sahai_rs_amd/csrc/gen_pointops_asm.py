@@ -16,11 +16,11 @@ by running the generated programs on integers).
 Register map of a subroutine (L = limbs: 14 BLS12-381, 10 BN254):
     block k = v[B+kL .. B+kL+L-1], k = 0..10, B = 48;  ACC = v[B+11L : B+11L+1], T = v[B+11L+2], HOUT = v[B+11L+3], v[B+11L+4]
     in / out:  X = block 0, Y = block 1, Z = block 2 (the running Jacobian point, updated IN PLACE)
-    madd only: qx = block 3, qy = block 4 (affine addend, destroyed); HOUT = limbs 0 and 1 of the normalised
-               H = U2 - X1 (the caller's cheap "H may be 0 mod p" filter: gs_fq28.cuh maybe_zero_limbs01)
+    madd only: qx = block 3, qy = block 4 (affine addend, destroyed); HOUT = FLAG (1: some lane may have H = U2 - X1 = 0
+               mod p, nothing was touched; s[60:61] = p^-1 mod 2^56 for that test)
     modulus in s40.. as for the multiplier subroutines, return address in s[34:35].
-The edge cases of the addition (either operand the identity, H = 0) are the CALLER's: it tests before / after the call
-and takes the C++ path on a saved copy (gs_curve.cuh, jac_madd_fast).
+The edge cases of the addition: an identity operand is the CALLER's (tested before the call); H = 0 is tested by the
+subroutine itself, which then returns with FLAG = 1 and every operand untouched (export_limb0; gs_curve.cuh jac_madd_ip).
 """
 import os
 
@@ -173,10 +173,43 @@ class Prog:
         self.ops.append(("norm", name, name, None))
 
     def export_limb0(self, name):
-        self.out.append("v_mov_b32 %s, %s" % (self.hout, self.r(self.b(name), 0)))
-        self.out.append("v_mov_b32 %s, %s" % (self.hout1, self.r(self.b(name), 1)))
+        """H = U2 - X1 = 0 mod p (P = +-Q) is the case the generic formulas do not cover: the 56-bit filter of gs_fq28.cuh
+        (maybe_zero_limbs01) on the two low limbs of H, HERE -- if any active lane may have H = 0 the subroutine returns
+        at once with FLAG = 1 and every operand as it came, and the caller sends the wave through the C++ addition.  (Round
+        4 first handed the two limbs back and tested after the call: the caller then kept copies of both operands alive
+        across every call -- seven 16-byte private-segment stores per addition step for a path taken once in 2^35.)
+        s[60:61] = p^-1 mod 2^56; temporaries: the accumulator, (T, HOUT) as a pair, HOUT1, limb 0 of block NB - 1."""
+        o, h = self.out, self.b(name)
+        top = BASE + NB * self.L
+        alo, ahi = "v%d" % top, "v%d" % (top + 1)
+        assert top % 2 == 0                     # (64-bit register pairs are even-aligned on this target)
+        k = "v[%d:%d]" % (top + 2, top + 3)      # (T, HOUT) as a pair
+        klo, khi = self.t, self.hout
+        x, y = self.r(NB - 1, 0), self.hout1
+        o.append("s_mov_b32 s62, 0x10000000")
+        o.append("v_mov_b32 %s, %s" % (alo, self.r(h, 0)))
+        o.append("v_ashrrev_i32 %s, 31, %s" % (ahi, self.r(h, 0)))
+        o.append("v_mad_i64_i32 %s, vcc, %s, s62, %s" % (self.acc, self.r(h, 1), self.acc))
+        o.append("v_mul_lo_u32 %s, %s, s61" % (y, alo))
+        o.append("v_mul_lo_u32 %s, %s, s60" % (x, ahi))
+        o.append("v_mad_u64_u32 %s, vcc, %s, s60, 0" % (k, alo))
+        o.append("v_add3_u32 %s, %s, %s, %s" % (khi, khi, y, x))
+        o.append("v_bfe_i32 %s, %s, 0, 24" % (khi, khi))
+        o.append("v_add_co_u32 %s, vcc, 0x100000, %s" % (klo, klo))
+        o.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (khi, khi))
+        o.append("v_cmp_eq_u32 vcc, 0, %s" % khi)
+        o.append("s_mov_b64 s[38:39], vcc")
+        o.append("v_cmp_ge_u32 vcc, 0x200000, %s" % klo)
+        o.append("s_and_b64 vcc, vcc, s[38:39]")
+        o.append("s_cbranch_vccz .Lgs_g1_go%d_%%=" % self.L)
+        o.append("v_mov_b32 %s, 1" % self.hout)
+        o.append("s_setpc_b64 s[34:35]")
+        o.append(".Lgs_g1_go%d_%%=:" % self.L)
+        self.has_flag = True
 
     def ret(self):
+        if getattr(self, "has_flag", False):
+            self.out.append("v_mov_b32 %s, 0" % self.hout)
         self.out.append("s_setpc_b64 s[34:35]")
 
 
@@ -226,16 +259,23 @@ def g1_madd(L):
     """the generic branch of jac_madd (madd-2007-bl, gs_curve.cuh): (X, Y, Z) += (qx, qy), in place"""
     p = Prog(L, "madd")
     p.pin("X", 0), p.pin("Y", 1), p.pin("Z", 2), p.pin("qx", 3), p.pin("qy", 4)
+    # The caller's own edge test (either operand the identity) arrives in T: if ANY active lane has it set, return at once
+    # (FLAG = 1, nothing touched) -- the call itself stays UNCONDITIONAL in the caller.  (A branch around the call made
+    # hipcc keep the running point in the private segment: 11 + 11 sixteen-byte accesses per addition step.)
+    p.out.append("v_cmp_ne_u32 vcc, 0, %s" % p.t)
+    p.out.append("s_cbranch_vccz .Lgs_g1_in%d_%%=" % L)
+    p.out.append("v_mov_b32 %s, 1" % p.hout)
+    p.out.append("s_setpc_b64 s[34:35]")
+    p.out.append(".Lgs_g1_in%d_%%=:" % L)
     p.sqr("z1z1", "Z")
     p.mul("u2", "qx", "z1z1")
-    p.free("qx")
     p.mul("t", "qy", "Z")
-    p.free("qy")
     p.mul("s2", "t", "z1z1")
     p.free("t")
     p.lin("sub", "h", "u2", "X", inplace=True)
     p.norm("h")
-    p.export_limb0("h")
+    p.export_limb0("h")       # (nothing handed in has been overwritten up to here: X, Y, Z, qx, qy are all in their blocks)
+    p.free("qx", "qy")
     p.lin("sub", "rr0", "s2", "Y", inplace=True)
     p.lin("dbl", "rr", "rr0", inplace=True)  # 4
     p.norm("rr")
@@ -302,15 +342,17 @@ def emit(L):
     o.append("}")
     # ---- mixed addition: X, Y, Z in / out, qx, qy in (destroyed), h0 out
     ios = ['"+{v%d}"(%s[%d])' % (BASE + k * L + i, nm, i) for k, nm in enumerate(("x", "y", "z", "qx", "qy")) for i in range(L)]
-    ios.append('"={v%d}"(h0)' % (BASE + NB * L + 3))
-    ios.append('"={v%d}"(h1)' % (BASE + NB * L + 4))
+    ios.append('"={v%d}"(flag)' % (BASE + NB * L + 3))  # 1: an edge lane or a possible H = 0 in the wave, nothing was touched
+    ios.append('"+{v%d}"(edge)' % (BASE + NB * L + 2))   # in: the caller's identity-operand test (T; destroyed)
     nout = len(ios)
-    clob = ['"v%d"' % r for r in range(BASE + scratch_lo, BASE + NB * L + 3)] + ['"vcc"', '"s34"', '"s35"']
+    clob = ['"v%d"' % r for r in range(BASE + scratch_lo, BASE + NB * L + 2)] + ['"v%d"' % (BASE + NB * L + 4)] + \
+        ['"vcc"', '"s34"', '"s35"', '"s38"', '"s39"', '"s62"']
+    modf = mod + ['"{s60}"((uint32_t)(pinv56<C>() & 0xffffffffu))', '"{s61}"((uint32_t)(pinv56<C>() >> 32))']
     o.append("template <class C> __device__ __forceinline__ void g1_madd_call_%d(int32_t (&x)[%d], int32_t (&y)[%d], int32_t (&z)[%d], "
-             "int32_t (&qx)[%d], int32_t (&qy)[%d], int32_t& h0, int32_t& h1) {" % (L, L, L, L, L, L))
-    o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (nout + len(mod)))
+             "int32_t (&qx)[%d], int32_t (&qy)[%d], int32_t& edge, int32_t& flag) {" % (L, L, L, L, L, L))
+    o.append('  asm("s_swappc_b64 s[34:35], %%%d"' % (nout + len(modf)))
     o.append("      : %s" % ", ".join(ios))
-    o.append("      : %s" % ", ".join(mod + ['"s"((uint64_t)(uintptr_t)&gs_g1_madd_sub_%d)' % L]))
+    o.append("      : %s" % ", ".join(modf + ['"s"((uint64_t)(uintptr_t)&gs_g1_madd_sub_%d)' % L]))
     o.append("      : %s);" % ", ".join(clob))
     o.append("}")
     stats = {nm: (len(p.out), p.peak) for nm, p in progs.items()}

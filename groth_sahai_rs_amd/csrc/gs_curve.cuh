@@ -138,11 +138,12 @@ template <class F> GS_JAC void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>&
 }
 
 // ---- fast in-place forms for the scalar-multiplication loops ----------------------------------------------------------
-// G1 on the device: the whole point operation is ONE generated subroutine on fixed registers (gs_pointops_asm.h: no
-// operand moves, no spills, no memory instruction).  The subroutine is the generic branch of the formulas; the edge
-// cases of the addition stay here: either operand the identity, or H = 0 mod p (P = +-Q), found by the 56-bit filter on
-// the two low limbs of H the subroutine hands back -- then the C++ jac_madd runs on the SAVED operands.  Everything else
-// (G2, the CPU twin, builds without the asm calls) takes the C++ formulas.
+// G1 / G2 on the device: the whole point operation is ONE generated subroutine on fixed registers (gs_pointops_asm.h:
+// G1 straight-line, no operand moves, no spills, no memory instruction; G2 the compact form around the shared Fp2
+// multiplier).  The subroutine is the generic branch of the formulas; the edge cases of the addition stay in C++: an
+// identity operand is tested before the call, H = 0 mod p (P = +-Q) by the subroutine itself (56-bit filter, early
+// return with the operands untouched) -- then the C++ jac_madd runs.  The CPU twin and builds without the asm calls
+// take the C++ formulas.
 template <class F> GS_HD_NOINLINE void jac_madd_edge(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) { jac_madd(r, p, q); }
 template <class F> GS_HD void jac_dbl_ip(Jac<F>& r) { jac_dbl(r, r); }
 template <class F> GS_HD void jac_madd_ip(Jac<F>& r, const Aff<F>& q) { jac_madd(r, r, q); }
@@ -155,21 +156,31 @@ template <class C> GS_HD void jac_dbl_ip(Jac<Fq<C>>& r) {
     g1_dbl_call_10<C>(r.x.v, r.y.v, r.z.v);
 }
 template <class C> GS_HD void jac_madd_ip(Jac<Fq<C>>& r, const Aff<Fq<C>>& q) {
-  const Jac<Fq<C>> p0 = r;
+  // The subroutine tests H = 0 ITSELF (56-bit filter, false alarms 2^-35 per lane) and returns at once, flag = 1, with
+  // both operands untouched when any active lane may have P = +-Q or has an identity operand (`edge`).  So nothing but
+  // the two operands is live across the call -- `r` never has its address taken (a running value that is
+  // only reachable through a reference is memory at every step): the out-of-line routine works on copies made in the
+  // rare branch.
   Aff<Fq<C>> qq = q;
-  const bool edge = aff_is_inf(q) || is_zero_limbs(r.z);
-  int32_t h0, h1;
+  int32_t flag, edge = (aff_is_inf(q) || is_zero_limbs(r.z)) ? 1 : 0;
+  // (the call is UNCONDITIONAL: the subroutine returns at once when any active lane has `edge` set)
   if constexpr (C::L == 14)
-    g1_madd_call_14<C>(r.x.v, r.y.v, r.z.v, qq.x.v, qq.y.v, h0, h1);
+    g1_madd_call_14<C>(r.x.v, r.y.v, r.z.v, qq.x.v, qq.y.v, edge, flag);
   else
-    g1_madd_call_10<C>(r.x.v, r.y.v, r.z.v, qq.x.v, qq.y.v, h0, h1);
-  if (edge || maybe_zero_limbs01<C>(h0, h1)) {  // rare: the first addition of a lane, identity table entries, P = +-Q
-    // (false alarms 2^-35).  `r` and `p0` never have their address taken -- a running value that is only reachable
-    // through a reference is memory at every step -- so the out-of-line routine works on copies made in this branch.
-    Jac<Fq<C>> tp = p0, tr;
-    Aff<Fq<C>> tq = q;
+    g1_madd_call_10<C>(r.x.v, r.y.v, r.z.v, qq.x.v, qq.y.v, edge, flag);
+  if (flag) {  // rare: the first addition of a lane, identity table entries, P = +-Q
+    // (limb by limb: a whole-struct copy FROM `r` is a memcpy from its address, and hipcc then keeps the running point
+    // in the private segment across the entire loop -- 11 loads before and 11 stores after every doubling call)
+    Jac<Fq<C>> tp, tr;
+    Aff<Fq<C>> tq;
+#pragma unroll
+    for (int i = 0; i < C::L; i++) {
+      tp.x.v[i] = r.x.v[i], tp.y.v[i] = r.y.v[i], tp.z.v[i] = r.z.v[i];
+      tq.x.v[i] = qq.x.v[i], tq.y.v[i] = qq.y.v[i];
+    }
     jac_madd_edge(tr, tp, tq);
-    r = tr;
+#pragma unroll
+    for (int i = 0; i < C::L; i++) r.x.v[i] = tr.x.v[i], r.y.v[i] = tr.y.v[i], r.z.v[i] = tr.z.v[i];
   }
 }
 #if defined(GS_POINT_ASM_G2) && !defined(GS_POINT_ASM_G2_STRAIGHT)
