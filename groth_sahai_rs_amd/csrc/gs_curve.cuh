@@ -288,26 +288,54 @@ template <class F> GS_HD_NOINLINE void smul_build_table(Jac<F>* tab, const Aff<F
 // psi, which conjugates Z, maps the isomorphic curve to itself.  Entries at infinity become the affine identity (0, 0).
 template <class C> GS_HD Fq<C> gz_adjust(const Fq<C>&) { return fq_one<C>(); }
 template <class C> GS_HD Fp2<C> gz_adjust(const Fp2<C>& zc) { return conj(zc); }
+// (helpers of the loop below: limb-wise loads into locals that never have their address taken by an out-of-line call --
+// a whole-struct copy from memory, or a value handed to is_zero()'s exact test by reference, makes hipcc keep the value in
+// the private segment and move it 16 bytes at a time with a full wait in between)
+template <class F> GS_HD void ld_limbs(F& d, const F* s) {
+  constexpr int NW = (int)(sizeof(F) / sizeof(limb_t));
+  const limb_t* w = reinterpret_cast<const limb_t*>(s);
+#pragma unroll
+  for (int q = 0; q < NW; q++) reinterpret_cast<limb_t*>(&d)[q] = w[q];
+}
+template <class C> GS_HD bool gz_maybe_zero(const Fq<C>& a) { return maybe_zero_limbs01<C>(a.v[0], a.v[1]); }
+template <class C> GS_HD bool gz_maybe_zero(const Fp2<C>& a) { return gz_maybe_zero<C>(a.c0) && gz_maybe_zero<C>(a.c1); }
+template <class C, class F> GS_HD bool gz_is_zero(const F& z) {
+  if (!gz_maybe_zero<C>(z)) return false;  // 56-bit filter, inline
+  F t = z;                                 // the exact test (out of line, by reference) works on a copy made HERE
+  return is_zero(t);
+}
 template <class C, class F> GS_HD_NOINLINE void table_global_z(Aff<F>* aff, const Jac<F>* tab, int M, F& zback) {
+  // Both passes read every entry ONCE from the lane's workspace (HBM): each entry is requested one iteration ahead, so
+  // that its latency hides behind the multiplications of the current one -- at one wave per SIMD a load issued where it
+  // is needed is 1-2 us of nothing, 2 x 128 times per table build (round 4: 13 % of the wave cycles of the 8-term G1
+  // lanes were s_waitcnt, most of them here).
   F acc = one_of<F>();
+  F zn;
+  ld_limbs(zn, &tab[0].z);
   for (int i = 0; i < M; i++) {
+    const F z = zn;
+    if (i + 1 < M) ld_limbs(zn, &tab[i + 1].z);
     aff[i].x = acc;  // prefix product, replaced below
-    if (!is_zero(tab[i].z)) acc = mul(acc, tab[i].z);
+    if (!gz_is_zero<C>(z)) acc = mul(acc, z);
   }
   F adj = gz_adjust<C>(acc);
   zback = mul(acc, adj);
   F suf = adj;
+  F ex, ey, ez, pre;
+  ld_limbs(ex, &tab[M - 1].x), ld_limbs(ey, &tab[M - 1].y), ld_limbs(ez, &tab[M - 1].z), ld_limbs(pre, &aff[M - 1].x);
   for (int i = M - 1; i >= 0; i--) {
-    if (is_zero(tab[i].z)) {
+    const F cx = ex, cy = ey, cz = ez, cp = pre;
+    if (i > 0) ld_limbs(ex, &tab[i - 1].x), ld_limbs(ey, &tab[i - 1].y), ld_limbs(ez, &tab[i - 1].z), ld_limbs(pre, &aff[i - 1].x);
+    if (gz_is_zero<C>(cz)) {
       aff[i].x = zero_of<F>();
       aff[i].y = zero_of<F>();
       continue;
     }
-    F sc = mul(aff[i].x, suf);
-    suf = mul(suf, tab[i].z);
+    F sc = mul(cp, suf);
+    suf = mul(suf, cz);
     F s2 = sqr(sc);
-    aff[i].x = mul(tab[i].x, s2);
-    aff[i].y = mul(tab[i].y, mul(s2, sc));
+    aff[i].x = mul(cx, s2);
+    aff[i].y = mul(cy, mul(s2, sc));
   }
 }
 
